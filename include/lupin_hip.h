@@ -1,0 +1,420 @@
+/*
+ * lupin_hip.h -- C ABI of the MI355X (gfx950) software-BVH path tracer that stands in for
+ * LupinPathTracer's `lp::pathtrace_scene()` hot path.
+ *
+ * Every struct below is byte-identical to the `#[repr(C)]` type the reference uploads to its
+ * WGSL megakernel, and every entry point names the reference interface it replaces
+ * (paths are relative to the reference checkout, `lupin/src/...`).
+ *
+ * Conventions (reference: renderer.rs:754-766, :768-842):
+ *   - handles are opaque, not thread-safe, one context per GPU;
+ *   - `lupin_hip_pathtrace_scene` ENQUEUES on the context's HIP stream and returns (the
+ *     reference does `queue.submit` and returns, renderer.rs:841); `lupin_hip_sync` or any
+ *     download is the sync point;
+ *   - no panics across the ABI: every call returns LUPIN_OK or a negative error code and
+ *     `lupin_hip_last_error()` holds the message (the reference asserts / panics instead,
+ *     renderer.rs:770,776,814);
+ *   - matrices are column-major f32, little-endian, exactly as base.rs:500-800 lays them out.
+ */
+#ifndef LUPIN_HIP_H
+#define LUPIN_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * Scene record layouts (renderer.rs:94-250 == pathtracer.wgsl:88-178)
+ * ---------------------------------------------------------------------------------------- */
+
+#define LUPIN_SENTINEL_IDX 0xFFFFFFFFu /* renderer.rs SENTINEL_IDX / pathtracer.wgsl:66 */
+
+/* base.rs:634  Mat3x4 { m: [[f32;3];4] }  -- 4 columns x 3 rows, last column = translation */
+typedef struct LupinMat3x4 { float m[4][3]; } LupinMat3x4;
+/* base.rs:763  Mat4x3 { m: [[f32;4];3] }  -- 3 columns x 4 rows */
+typedef struct LupinMat4x3 { float m[3][4]; } LupinMat4x3;
+/* base.rs:505  Mat4 { m: [[f32;4];4] } column-major */
+typedef struct LupinMat4 { float m[4][4]; } LupinMat4;
+
+/* renderer.rs:94-100 */
+typedef struct LupinMeshInfo {
+    uint32_t normals_buf_idx;
+    uint32_t texcoords_buf_idx;
+    uint32_t colors_buf_idx;
+} LupinMeshInfo;
+
+/* renderer.rs:115-124 ; 64 bytes. transpose_inverse_transform = rows of the world->local affine. */
+typedef struct LupinInstance {
+    LupinMat4x3 transpose_inverse_transform;
+    uint32_t mesh_idx;
+    uint32_t mat_idx;
+    float _padding0;
+    float _padding1;
+} LupinInstance;
+
+/* renderer.rs:126-139 */
+enum LupinMaterialType {
+    LUPIN_MAT_MATTE = 0,
+    LUPIN_MAT_GLOSSY = 1,
+    LUPIN_MAT_REFLECTIVE = 2,
+    LUPIN_MAT_TRANSPARENT = 3,
+    LUPIN_MAT_REFRACTIVE = 4,
+    LUPIN_MAT_SUBSURFACE = 5,
+    LUPIN_MAT_VOLUMETRIC = 6,
+    LUPIN_MAT_GLTFPBR = 7
+};
+
+/* renderer.rs:141-161 ; 96 bytes */
+typedef struct LupinMaterial {
+    float color[4];      /* w = opacity */
+    float emission[4];
+    float scattering[4];
+    uint32_t mat_type;
+    float roughness;
+    float metallic;
+    float ior;
+    float sc_anisotropy;
+    float tr_depth;
+    uint32_t color_tex_idx;
+    uint32_t emission_tex_idx;
+    uint32_t roughness_tex_idx;
+    uint32_t scattering_tex_idx;
+    uint32_t normal_tex_idx;
+    uint32_t padding0;
+} LupinMaterial;
+
+/* renderer.rs:187-194 ; 80 bytes */
+typedef struct LupinEnvironment {
+    float emission[3];
+    uint32_t emission_tex_idx;
+    LupinMat4 transform;
+} LupinEnvironment;
+
+/* renderer.rs:208-214 */
+typedef struct LupinLight {
+    uint32_t instance_idx;
+    float area;
+} LupinLight;
+
+/* renderer.rs:216-223 */
+typedef struct LupinAliasBin {
+    float prob;
+    float alias_threshold;
+    uint32_t alias;
+} LupinAliasBin;
+
+/* renderer.rs:228-238 ; 32 bytes. tri_count == 0 => internal node, children at first_child, +1 */
+typedef struct LupinBvhNode {
+    float aabb_min[3];
+    uint32_t tri_begin_or_first_child;
+    float aabb_max[3];
+    uint32_t tri_count;
+} LupinBvhNode;
+
+/* renderer.rs:240-250 ; 48 bytes. left == 0 => leaf */
+typedef struct LupinTlasNode {
+    float aabb_min[3];
+    uint32_t left;
+    float aabb_max[3];
+    uint32_t instance_idx;
+    uint32_t right;
+    float _padding0[3];
+} LupinTlasNode;
+
+/* renderer.rs:252-280 ; 128 bytes. Exposed because the oracle and the kernels consume exactly
+ * this record; hosts normally never build it (lupin_hip_pathtrace_scene does, like
+ * get_push_constants{,_tiled}, renderer.rs:1426-1506). */
+typedef struct LupinPushConstants {
+    LupinMat4 camera_transform;
+    float camera_lens;
+    float camera_film;
+    float camera_aspect;
+    float camera_focus;
+    float camera_aperture;
+    uint32_t flags;
+    uint32_t id_offset[2];
+    uint32_t accum_counter;
+    float heatmap_min;
+    float heatmap_max;
+    uint32_t falsecolor_type;
+    uint32_t pathtrace_type;
+    float max_radiance;
+    uint32_t rng_seed;   /* never read by the shader (pathtracer.wgsl:1565) -- kept for layout */
+    float ray_epsilon;
+} LupinPushConstants;
+
+/* renderer.rs:284-291 */
+#define LUPIN_FLAG_CAMERA_ORTHO         (1u << 0)
+#define LUPIN_FLAG_ENVS_EMPTY           (1u << 1)
+#define LUPIN_FLAG_LIGHTS_EMPTY         (1u << 2)
+#define LUPIN_FLAG_DEBUG_TRI_CHECKS     (1u << 3)
+#define LUPIN_FLAG_DEBUG_AABB_CHECKS    (1u << 4)
+#define LUPIN_FLAG_DEBUG_NUM_BOUNCES    (1u << 5)
+#define LUPIN_FLAG_DEBUG_FIRST_HIT_ONLY (1u << 6)
+#define LUPIN_FLAG_INSTANCES_EMPTY      (1u << 7)
+
+/* renderer.rs:294-305 */
+#define LUPIN_BVH_MAX_DEPTH   25
+#define LUPIN_TLAS_MAX_DEPTH  50
+#define LUPIN_WORKGROUP_SIZE  4   /* tile_size is counted in 4x4-pixel workgroups */
+#define LUPIN_MAX_ENVS        10
+
+/* Texture formats the loader produces (lupin_loader/src/loader.rs:227-231): LDR = Rgba8Unorm
+ * (never ...Srgb, decode happens in the shader), HDR = Rgba16Float. One mip, bilinear, Repeat
+ * in u and v (wgpu_utils.rs:244-256). */
+enum LupinTextureFormat {
+    LUPIN_TEX_RGBA8_UNORM = 0,
+    LUPIN_TEX_RGBA16_FLOAT = 1
+};
+
+typedef struct LupinTextureDesc {
+    uint32_t width;
+    uint32_t height;
+    uint32_t format;       /* LupinTextureFormat */
+    const void *pixels;    /* host pointer, row-major, 4 B or 8 B per texel */
+} LupinTextureDesc;
+
+/* One mesh = the per-mesh storage buffers of lp::Scene in its software-BVH configuration
+ * (renderer.rs:17-60): positions (Vec4, stride 16), BVH-reordered indices, BLAS nodes. */
+typedef struct LupinMeshDesc {
+    const float *verts_pos;          /* num_verts * 4 floats (w ignored) */
+    uint32_t num_verts;
+    const uint32_t *indices;         /* num_indices u32, triangles in BLAS leaf order */
+    uint32_t num_indices;
+    const LupinBvhNode *bvh_nodes;
+    uint32_t num_bvh_nodes;
+} LupinMeshDesc;
+
+typedef struct LupinVertexBufferDesc {
+    const float *data;               /* normals/colours: 4 floats per vertex; texcoords: 2 */
+    uint32_t num_verts;
+} LupinVertexBufferDesc;
+
+typedef struct LupinAliasTableDesc {
+    const LupinAliasBin *bins;
+    uint32_t num_bins;
+} LupinAliasTableDesc;
+
+/* Flat restatement of lp::Scene (renderer.rs:17-60) for the software-BVH pipeline. All pointers
+ * are host pointers, copied during lupin_hip_scene_create. */
+typedef struct LupinSceneDesc {
+    const LupinMeshInfo *mesh_infos;         /* num_meshes entries */
+    const LupinMeshDesc *meshes;
+    uint32_t num_meshes;
+
+    const LupinVertexBufferDesc *verts_normal_array;
+    uint32_t num_normal_buffers;
+    const LupinVertexBufferDesc *verts_texcoord_array;
+    uint32_t num_texcoord_buffers;
+    const LupinVertexBufferDesc *verts_color_array;
+    uint32_t num_color_buffers;
+
+    const LupinInstance *instances;
+    uint32_t num_instances;
+    const LupinMaterial *materials;
+    uint32_t num_materials;
+    const LupinTextureDesc *textures;
+    uint32_t num_textures;
+    const LupinEnvironment *environments;
+    uint32_t num_environments;
+
+    const LupinTlasNode *tlas_nodes;
+    uint32_t num_tlas_nodes;
+
+    const LupinLight *lights;
+    uint32_t num_lights;
+    const LupinAliasTableDesc *alias_tables;      /* num_lights tables */
+    const LupinAliasTableDesc *env_alias_tables;  /* num_environments tables */
+} LupinSceneDesc;
+
+/* ------------------------------------------------------------------------------------------
+ * Call-surface structs (renderer.rs:451-468, :644-766)
+ * ---------------------------------------------------------------------------------------- */
+
+/* renderer.rs:451-468 (defaults false, 8, 5) */
+typedef struct LupinBakedPathtraceParams {
+    uint32_t with_runtime_checks;   /* accepted, no effect: HIP kernels have no naga bounds checks */
+    uint32_t max_bounces;
+    uint32_t samples_per_pixel;
+} LupinBakedPathtraceParams;
+
+/* renderer.rs:683-708 (defaults 0, .050, .036, 1.5, 10000, 0) */
+typedef struct LupinCameraParams {
+    uint32_t is_orthographic;
+    float lens;
+    float film;
+    float aspect;
+    float focus;
+    float aperture;
+} LupinCameraParams;
+
+/* renderer.rs:711-729 */
+enum LupinPathtraceType {
+    LUPIN_PATHTRACE_STANDARD = 0,
+    LUPIN_PATHTRACE_MIS = 1,
+    LUPIN_PATHTRACE_NAIVE = 2,
+    LUPIN_PATHTRACE_DIRECT = 3
+};
+
+/* renderer.rs:731-749 (defaults 100, 0, 0.001) */
+typedef struct LupinAdvancedParams {
+    float max_radiance;
+    uint32_t rng_seed;
+    float ray_epsilon;
+} LupinAdvancedParams;
+
+/* renderer.rs:651-670 (defaults 100, 0) */
+typedef struct LupinTileParams {
+    uint32_t tile_size;   /* in 4-pixel workgroups */
+    uint32_t tile_idx;
+} LupinTileParams;
+
+typedef struct LupinContext LupinContext;
+typedef struct LupinPathtraceResources LupinPathtraceResources;
+typedef struct LupinScene LupinScene;
+typedef struct LupinTexture LupinTexture;                     /* one Rgba16Float render target */
+typedef struct LupinDoubleBufferedTexture LupinDoubleBufferedTexture;
+
+/* renderer.rs:644-649 */
+typedef struct LupinAccumulationParams {
+    const LupinTexture *prev_frame;
+    uint32_t accum_counter;
+} LupinAccumulationParams;
+
+/* renderer.rs:751-766. Option<> fields become nullable pointers. */
+typedef struct LupinPathtraceDesc {
+    const LupinAccumulationParams *accum_params;   /* NULL = None */
+    const LupinTileParams *tile_params;            /* NULL = None (full-screen dispatch) */
+    LupinCameraParams camera_params;
+    LupinMat3x4 camera_transform;
+    uint32_t force_software_bvh;                   /* both values select the software BVH here */
+    LupinAdvancedParams advanced;
+} LupinPathtraceDesc;
+
+enum LupinStatus {
+    LUPIN_OK = 0,
+    LUPIN_ERR_INVALID_ARGUMENT = -1,
+    LUPIN_ERR_NO_DEVICE = -2,        /* no HIP device / extension unusable: there is NO CPU fallback */
+    LUPIN_ERR_HIP = -3,
+    LUPIN_ERR_NO_SW_BVH = -4,        /* renderer.rs:774-777 */
+    LUPIN_ERR_TILE_OUT_OF_RANGE = -5,/* renderer.rs:814 */
+    LUPIN_ERR_SAME_TARGET = -6,      /* render_target == prev_frame, renderer.rs:754-755 */
+    LUPIN_ERR_OUT_OF_MEMORY = -7
+};
+
+/* ------------------------------------------------------------------------------------------
+ * Entry points
+ * ---------------------------------------------------------------------------------------- */
+
+const char *lupin_hip_last_error(void);
+/* number of visible HIP devices; 0 when none (never initialises a context) */
+int lupin_hip_device_count(void);
+
+/* wgpu device/queue acquisition (wgpu_utils.rs:20-120, renderer.rs:307-330) -> one HIP device + stream */
+int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx);
+void lupin_hip_destroy_context(LupinContext *ctx);
+/* device.poll(wait_indefinitely) (loader.rs:1692,1825) */
+int lupin_hip_sync(LupinContext *ctx);
+
+/* lp::build_pathtrace_resources (renderer.rs:470-642): bakes max_bounces / samples_per_pixel */
+int lupin_hip_build_pathtrace_resources(LupinContext *ctx, const LupinBakedPathtraceParams *params,
+                                        LupinPathtraceResources **out_res);
+void lupin_hip_destroy_pathtrace_resources(LupinPathtraceResources *res);
+
+/* upload half of lp::build_accel_structures_and_upload (data_structures.rs:696-872) */
+int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinScene **out_scene);
+void lupin_hip_scene_destroy(LupinScene *scene);
+
+/* Rgba16Float render targets + lp::DoubleBufferedTexture (wgpu_utils.rs:279-348) */
+int lupin_hip_texture_create(LupinContext *ctx, uint32_t width, uint32_t height, LupinTexture **out_tex);
+void lupin_hip_texture_destroy(LupinTexture *tex);
+uint32_t lupin_hip_texture_width(const LupinTexture *tex);
+uint32_t lupin_hip_texture_height(const LupinTexture *tex);
+/* raw device pointer of the W*H*4 half-float payload (row-major, row 0 = top) for zero-copy
+ * wrapping by the host (e.g. RCCL gather of tile payloads) */
+void *lupin_hip_texture_device_ptr(const LupinTexture *tex);
+int lupin_hip_texture_upload_rgba16f(LupinTexture *tex, const uint16_t *pixels);
+/* readback (loader.rs:1775-1879 download path); synchronises the stream */
+int lupin_hip_texture_download_rgba16f(const LupinTexture *tex, uint16_t *out_pixels);
+
+int lupin_hip_dbuf_create(LupinContext *ctx, uint32_t width, uint32_t height,
+                          LupinDoubleBufferedTexture **out);          /* wgpu_utils.rs:289 */
+void lupin_hip_dbuf_destroy(LupinDoubleBufferedTexture *t);
+LupinTexture *lupin_hip_dbuf_front(LupinDoubleBufferedTexture *t);    /* :301 */
+LupinTexture *lupin_hip_dbuf_back(LupinDoubleBufferedTexture *t);     /* :306 */
+int lupin_hip_dbuf_copy_front_to_back(LupinDoubleBufferedTexture *t); /* :321 */
+void lupin_hip_dbuf_flip(LupinDoubleBufferedTexture *t);              /* :334 */
+int lupin_hip_dbuf_resize(LupinDoubleBufferedTexture *t, uint32_t width, uint32_t height); /* :341 */
+
+/* lp::get_num_tiles (renderer.rs:675-681) */
+uint32_t lupin_hip_get_num_tiles(uint32_t tile_size, uint32_t width, uint32_t height);
+
+/* lp::pathtrace_scene (renderer.rs:768-842) */
+int lupin_hip_pathtrace_scene(LupinContext *ctx, const LupinPathtraceResources *res,
+                              const LupinScene *scene, LupinTexture *render_target,
+                              uint32_t pathtrace_type, const LupinPathtraceDesc *desc);
+
+/* ---- measurement hooks (no reference counterpart; the reference exposes none) ---- */
+
+typedef struct LupinStats {
+    uint64_t path_bounces;      /* integrator iterations that issued a closest-hit query (metric unit) */
+    uint64_t paths;             /* camera samples started */
+    uint64_t extend_launches;   /* launches of the dominant (extend) kernel */
+    double extend_ms;           /* summed hipEvent duration of those launches (0 unless timing on) */
+    double shade_ms;
+    double total_ms;            /* whole pathtrace_scene device time (timing on) */
+} LupinStats;
+/* reset + enable/disable per-kernel hipEvent timing (timing adds event records to the stream) */
+int lupin_hip_stats_reset(LupinContext *ctx, int enable_kernel_timing);
+/* synchronises, then reports totals since the last reset */
+int lupin_hip_stats_get(LupinContext *ctx, LupinStats *out);
+
+/* Standalone closest-hit probe over a ray batch: the traversal kernel alone
+ * (bvh_custom.wgsl:7-110). Host arrays; n rays; outputs hit(0/1), dst, u, v, instance, tri. */
+int lupin_hip_trace_rays(LupinContext *ctx, const LupinScene *scene, uint32_t n,
+                         const float *ori_xyz, const float *dir_xyz, float ray_epsilon,
+                         uint32_t *out_hit, float *out_dst, float *out_uv,
+                         uint32_t *out_instance, uint32_t *out_tri);
+
+/* Tile-sharded multi-GPU support: pack the pixels of every tile t with t % world == rank (tiles
+ * of tile_size*4 pixels, row-major tile order as renderer.rs:816-817) into a dense device
+ * buffer / scatter a packed buffer back. Payload layout: tiles in ascending t, each tile
+ * row-major, 8 B per pixel. Returns the number of pixels via out_pixels. */
+int lupin_hip_pack_tiles(LupinContext *ctx, const LupinTexture *tex, uint32_t tile_size,
+                         uint32_t rank, uint32_t world, void *device_dst, uint64_t *out_pixels);
+int lupin_hip_unpack_tiles(LupinContext *ctx, LupinTexture *tex, uint32_t tile_size,
+                           uint32_t rank, uint32_t world, const void *device_src);
+uint64_t lupin_hip_packed_tile_pixels(uint32_t width, uint32_t height, uint32_t tile_size,
+                                      uint32_t rank, uint32_t world);
+
+/* ------------------------------------------------------------------------------------------
+ * CPU-side preprocessing that produces the path's inputs (data_structures.rs:20-641).
+ * Pure host code, no device needed.
+ * ---------------------------------------------------------------------------------------- */
+
+/* build_bvh (data_structures.rs:196-235): reorders `indices` in place; returns node count or <0.
+ * out_nodes may be NULL to query the count (indices untouched in that case). */
+int64_t lupin_build_bvh(const float *verts_pos4, uint32_t num_verts, uint32_t *indices,
+                        uint32_t num_indices, LupinBvhNode *out_nodes, uint64_t out_capacity);
+/* build_tlas (data_structures.rs:545-641): out_nodes must hold 2*num_instances entries.
+ * model_aabbs: per mesh 6 floats (min xyz, max xyz). */
+int64_t lupin_build_tlas(const LupinInstance *instances, uint32_t num_instances,
+                         const float *model_aabbs, uint32_t num_meshes, LupinTlasNode *out_nodes);
+/* build_alias_table (data_structures.rs:116-193): returns bins written (0 when sum == 0) */
+int64_t lupin_build_alias_table(const float *weights, uint64_t n, LupinAliasBin *out_bins);
+/* triangle-area weights + total area of build_lights' inner loop (data_structures.rs:40-51,106-112) */
+float lupin_mesh_light_weights(const float *verts_pos4, const uint32_t *indices, uint32_t num_indices,
+                               float *out_weights);
+/* environment texel weights of build_lights (data_structures.rs:65-93); texels = w*h*4 f32 */
+void lupin_env_light_weights(const float *texels_rgba_f32, uint32_t width, uint32_t height,
+                             const float scale_rgb[3], float *out_weights);
+/* Mat3x4 inverse through Mat4::inverse (base.rs:542-578, :708-722) */
+void lupin_mat3x4_inverse(const LupinMat3x4 *in, LupinMat3x4 *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LUPIN_HIP_H */

@@ -1,0 +1,1391 @@
+// lupin_hip.hip -- wavefront path-tracing kernels for gfx950 + the C ABI of include/lupin_hip.h.
+//
+// What the reference runs as ONE megakernel invocation per pixel (`pathtrace_main`,
+// pathtracer.wgsl:220-292) is split here into stages over compacted queues of live paths:
+//
+//   k_begin      RNG seeding, first camera ray of every pixel of the dispatch      (:224-237, :505-542)
+//   k_extend     closest hit with stochastic alpha skipping                       (bvh_custom.wgsl:154-180)
+//   k_shade      the rest of one integrator-loop iteration: medium sampling, material fetch,
+//                emission, BSDF / light sampling + pdfs, volume stack, Russian roulette, and --
+//                when a path ends -- clamp_radiance, next camera sample of the same pixel
+//                (the per-pixel RNG stream continues across samples, :234-239), or retirement
+//   k_resolve    /spp, progressive blend with prev_frame, Rgba16Float store          (:275-289)
+//
+// One thread owns one pixel for the whole call, so radiance accumulation needs no atomics; the
+// only atomics are the per-wave queue appends (ballot + one atomicAdd per wave).
+//
+// THERE IS NO CPU FALLBACK: without a HIP device every entry point that needs one fails with
+// LUPIN_ERR_NO_DEVICE.
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+#include "lupin_device.hpp"
+
+using namespace lpd;
+
+// ------------------------------------------------------------------------------------------------
+// Path state (SoA over the pixels of one dispatch; slot = pixel of the dispatch region)
+// ------------------------------------------------------------------------------------------------
+
+// meta word: bounce [0,12) | flags [12,16) | sample [16,32)
+constexpr uint32_t META_BOUNCE_MASK = 0xFFFu;
+constexpr uint32_t META_VOLUME = 1u << 12;         // volume_stack_len == 1
+constexpr uint32_t META_NEXT_EMISSION = 1u << 13;  // MIS / Direct `next_emission`
+constexpr uint32_t META_SAMPLE_SHIFT = 16;
+constexpr uint32_t HIT_MISS = 0xFFFFFFFFu;
+
+struct PathBuffers
+{
+    float4 *ori_rng;    // ori.xyz | rng state
+    float4 *dir_meta;   // dir.xyz | meta
+    float4 *weight;     // weight.xyz
+    float4 *radiance;   // radiance.xyz
+    float4 *color;      // per-pixel sum over samples
+    float4 *hit;        // dst u v | instance (HIT_MISS = no hit)
+    uint32_t *hit_tri;  // global triangle
+    float4 *vol0;       // medium density.xyz | anisotropy
+    float4 *vol1;       // medium scattering.xyz
+    float4 *next_hit;   // MIS: hit of the BSDF-sampled shadow ray, reused as next vertex
+    uint32_t *next_tri;
+    uint32_t *queue[2];
+    uint32_t *counts;   // counts[k] = live paths entering iteration k
+};
+
+struct FrameParams
+{
+    LupinPushConstants pc;
+    uint32_t width, height;      // full image (RNG seeding uses the full width, :226)
+    uint32_t off_x, off_y;       // dispatch origin (id_offset)
+    uint32_t reg_w, reg_h;       // in-bounds pixels of the dispatch
+    uint32_t max_bounces, spp;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Camera (compute_camera_ray, pathtracer.wgsl:505-542) -- draws 2 (jitter) + 2 (lens) numbers
+// ------------------------------------------------------------------------------------------------
+
+__device__ void camera_ray(const FrameParams &fp, uint32_t gx, uint32_t gy, uint32_t &rng, f3 &ori, f3 &dir)
+{
+    const LupinPushConstants &pc = fp.pc;
+    float j0 = rnd(rng), j1 = rnd(rng);
+    float offx = j0 - 0.5f, offy = j1 - 0.5f;
+    float resx = (float)fp.width, resy = (float)fp.height;
+    float pcx = (float)gx + 0.5f, pcy = (resy - (float)gy) + 0.5f;
+    float uvx = (pcx + offx) / resx, uvy = (pcy + offy) / resy;
+
+    float lens = pc.camera_lens, film = pc.camera_film, aspect = pc.camera_aspect;
+    float focus = pc.camera_focus, aperture = pc.camera_aperture;
+    float fsx = (aspect >= 1.0f) ? film : film * aspect;
+    float fsy = (aspect >= 1.0f) ? film / aspect : film;
+    // random_in_disk (:1623-1629)
+    float d0 = rnd(rng), d1 = rnd(rng);
+    float dr = sqrtf(d1);
+    float ds, dc;
+    lpm_sincosf(2.0f * LP_PI * d0, &ds, &dc);
+    float lux = dc * dr, luy = ds * dr;
+
+    f3 e, d;
+    if (pc.flags & LUPIN_FLAG_CAMERA_ORTHO)
+    {
+        float sc = 1.0f / lens;
+        f3 q = mk3(fsx * (0.5f - uvx) * sc, fsy * (0.5f - uvy) * sc, lens);
+        e = add(mk3(-q.x, -q.y, 0.0f), mk3(lux * aperture / 2.0f, luy * aperture / 2.0f, 0.0f));
+        f3 p = mk3(-q.x, -q.y, -focus);
+        d = mul(normalize3(sub(p, e)), mk3(1.0f, 1.0f, -1.0f));
+    }
+    else
+    {
+        f3 q = mk3(fsx * (0.5f - uvx), fsy * (0.5f - uvy), lens);
+        f3 look_at = neg(normalize3(q));
+        e = mk3(lux * (aperture / 2.0f), luy * (aperture / 2.0f), 0.0f);
+        f3 focus_point = divs(scale(look_at, focus), fabsf(look_at.z));
+        d = mul(normalize3(sub(focus_point, e)), mk3(1.0f, 1.0f, -1.0f));
+    }
+    // transform_ray by camera_transform (:2662-2669): point without w-divide, direction normalised
+    const float (*m)[4] = pc.camera_transform.m;
+    ori = mk3(m[0][0] * e.x + m[1][0] * e.y + m[2][0] * e.z + m[3][0] * 1.0f,
+              m[0][1] * e.x + m[1][1] * e.y + m[2][1] * e.z + m[3][1] * 1.0f,
+              m[0][2] * e.x + m[1][2] * e.y + m[2][2] * e.z + m[3][2] * 1.0f);
+    dir = normalize3(mk3(m[0][0] * d.x + m[1][0] * d.y + m[2][0] * d.z + m[3][0] * 0.0f,
+                         m[0][1] * d.x + m[1][1] * d.y + m[2][1] * d.z + m[3][1] * 0.0f,
+                         m[0][2] * d.x + m[1][2] * d.y + m[2][2] * d.z + m[3][2] * 0.0f));
+}
+
+__device__ __forceinline__ void slot_to_pixel(const FrameParams &fp, uint32_t slot, uint32_t &gx, uint32_t &gy)
+{
+    gx = fp.off_x + slot % fp.reg_w;
+    gy = fp.off_y + slot / fp.reg_w;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage kernels
+// ------------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(LP_BLOCK) k_begin(FrameParams fp, PathBuffers pb, uint32_t n)
+{
+    uint32_t slot = blockIdx.x * LP_BLOCK + threadIdx.x;
+    if (slot == 0) pb.counts[0] = n;
+    if (slot >= n) return;
+    uint32_t gx, gy;
+    slot_to_pixel(fp, slot, gx, gy);
+    uint32_t rng = rng_seed_for(gy * fp.width + gx, fp.pc.accum_counter);
+    f3 o, d;
+    camera_ray(fp, gx, gy, rng, o, d);
+    pb.ori_rng[slot] = make_float4(o.x, o.y, o.z, __uint_as_float(rng));
+    pb.dir_meta[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(META_NEXT_EMISSION));
+    pb.weight[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    pb.radiance[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    pb.color[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    pb.next_hit[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(HIT_MISS));   // `var next_intersection = HitInfo()` (:746)
+    pb.next_tri[slot] = 0u;
+    pb.queue[0][slot] = slot;
+}
+
+// ray_skip_alpha_stochastically (bvh_custom.wgsl:154-180).  The material is consulted only for
+// instances whose opacity can differ from 1 (flag set at upload); for all others
+// opacity == 1 exactly, so `opacity < 1` is false and no random number is drawn -- identical to
+// the reference, which evaluates get_material_point for every hit.
+template <int TYPE>
+__global__ void __launch_bounds__(LP_BLOCK) k_extend(SceneDev sc, FrameParams fp, PathBuffers pb, uint32_t iter,
+                                                     unsigned long long *path_bounce_counter)
+{
+    extern __shared__ uint32_t lds_stack[];
+    const uint32_t count = pb.counts[iter];
+    const uint32_t i = blockIdx.x * LP_BLOCK + threadIdx.x;
+    if (i == 0 && count) atomicAdd(path_bounce_counter, (unsigned long long)count);
+    if (i >= count) return;
+    const uint32_t slot = pb.queue[iter & 1][i];
+
+    float4 orr = pb.ori_rng[slot];
+    float4 dm = pb.dir_meta[slot];
+    if (TYPE == LUPIN_PATHTRACE_MIS)
+    {
+        if (!(__float_as_uint(dm.w) & META_NEXT_EMISSION))
+        {
+            pb.hit[slot] = pb.next_hit[slot];
+            pb.hit_tri[slot] = pb.next_tri[slot];
+            return;
+        }
+    }
+    f3 o = mk3(orr.x, orr.y, orr.z), d = mk3(dm.x, dm.y, dm.z);
+    uint32_t rng = __float_as_uint(orr.w);
+    const uint32_t rng_in = rng;
+    const float eps = fp.pc.ray_epsilon;
+
+    float total = 0.0f;
+    Closest c;
+    c.t = LP_F32_MAX; c.u = 0.0f; c.v = 0.0f; c.tri = 0u; c.inst = HIT_MISS;
+    bool hit = false;
+    for (uint32_t k = 0; k < 128u; k++)   // MAX_OPACITY_BOUNCES (pathtracer.wgsl:1263)
+    {
+        c = scene_closest(sc, lds_stack, o, d, eps);
+        hit = (c.t != LP_F32_MAX);
+        if (!hit) break;
+        total += c.t;
+        if (!(sc.instances[c.inst].flags & 1u)) break;
+        Surface s = resolve_surface(sc, c.inst, c.tri, c.u, c.v);
+        float opacity = surface_opacity(sc, s);
+        if (opacity < 1.0f && rnd(rng) >= opacity) o = add(o, scale(d, c.t));
+        else break;
+    }
+    pb.hit[slot] = make_float4(total, c.u, c.v, __uint_as_float(hit ? c.inst : HIT_MISS));
+    pb.hit_tri[slot] = c.tri;
+    if (rng != rng_in) pb.ori_rng[slot].w = __uint_as_float(rng);
+}
+
+// clamp_radiance (pathtracer.wgsl:1774-1783)
+__device__ __forceinline__ f3 clamp_radiance(f3 r, float max_radiance)
+{
+    if (!finite3(r)) r = splat(0.0f);
+    if (r.x > max_radiance || r.y > max_radiance || r.z > max_radiance)
+        r = scale(r, max_radiance / maxf(r.x, maxf(r.y, r.z)));
+    return r;
+}
+
+struct PathRegs
+{
+    f3 ori, dir, weight, radiance;
+    uint32_t rng;
+    int bounce;
+    bool in_medium;       // volume_stack_len == 1
+    bool next_emission;
+    Medium medium;
+};
+
+// One iteration of the integrator loop body after the closest-hit query.  Returns true when the
+// path continues with (ori, dir) set for the next bounce, false on `break`.
+// TYPE 0: pathtrace_standard (:588-733)   1: pathtrace_mis (:737-933)
+//      2: pathtrace_naive (:942-1059)     3: pathtrace_direct (:1062-1245)
+template <int TYPE>
+__device__ bool integrate_vertex(const SceneDev &sc, uint32_t *stack, const FrameParams &fp, PathRegs &p,
+                                 float4 hitrec, uint32_t hit_tri, PathBuffers &pb, uint32_t slot)
+{
+    const float eps = fp.pc.ray_epsilon;
+    const uint32_t hit_inst = __float_as_uint(hitrec.w);
+    if (hit_inst == HIT_MISS)
+    {
+        if (TYPE != LUPIN_PATHTRACE_DIRECT || p.next_emission)
+            p.radiance = add(p.radiance, mul(p.weight, environment_radiance(sc, p.dir)));
+        return false;
+    }
+    const float hit_dst = hitrec.x;
+
+    // transmission inside a medium (:611-621)
+    bool in_volume = false;
+    float volume_dst = hit_dst;
+    if (p.in_medium)
+    {
+        float r1 = rnd(p.rng);
+        float r2 = rnd(p.rng);
+        volume_dst = medium_sample_distance(p.medium.density, hit_dst, r1, r2);
+        f3 tr = medium_transmittance(p.medium.density, volume_dst);
+        float tp = medium_distance_pdf(p.medium.density, volume_dst, hit_dst);
+        p.weight = mul(p.weight, divs(tr, tp));
+        in_volume = volume_dst < hit_dst;
+    }
+
+    const f3 outgoing = neg(p.dir);
+    f3 incoming = splat(0.0f);
+    f3 hit_pos;
+    if (!in_volume)
+    {
+        hit_pos = add(p.ori, scale(p.dir, hit_dst));
+        const Surface s = resolve_surface(sc, hit_inst, hit_tri, hitrec.y, hitrec.z);
+        const MatPoint mp = material_point(sc, s);
+        const f3 normal = shading_normal(sc, s);
+
+        if (TYPE == LUPIN_PATHTRACE_STANDARD || TYPE == LUPIN_PATHTRACE_NAIVE || p.next_emission)
+            p.radiance = add(p.radiance, mul(p.weight, mp.emission));
+
+        const bool delta = mat_is_delta(mp);
+
+        if (TYPE == LUPIN_PATHTRACE_DIRECT)   // light ray before choosing the continuation (:1117-1146)
+        {
+            if (!delta)
+            {
+                f3 li = lights_sample(sc, hit_pos, p.rng);
+                float pdf = lights_pdf(sc, stack, hit_pos, li, eps);
+                f3 bsdfcos = bsdf_eval(mp, normal, outgoing, li);
+                if (none_zero3(bsdfcos) && pdf > 0.0f)
+                {
+                    Closest lc = scene_closest(sc, stack, hit_pos, li, eps);
+                    f3 emission;
+                    if (lc.t != LP_F32_MAX)
+                        emission = material_point(sc, resolve_surface(sc, lc.inst, lc.tri, lc.u, lc.v)).emission;
+                    else
+                        emission = environment_radiance(sc, li);
+                    p.radiance = add(p.radiance, divs(mul(mul(p.weight, bsdfcos), emission), pdf));
+                }
+                p.next_emission = false;
+            }
+            else p.next_emission = true;
+        }
+
+        if (!delta)
+        {
+            if (TYPE == LUPIN_PATHTRACE_STANDARD || TYPE == LUPIN_PATHTRACE_DIRECT)
+            {
+                // one-sample mixture of BSDF and light sampling (:640-657)
+                if (rnd(p.rng) < 0.5f)
+                {
+                    float rnl = rnd(p.rng);
+                    float ra = rnd(p.rng), rb = rnd(p.rng);
+                    incoming = bsdf_sample(mp, normal, outgoing, rnl, ra, rb);
+                }
+                else incoming = lights_sample(sc, hit_pos, p.rng);
+                if (is_zero3(incoming)) return false;
+                float prob = 0.5f * bsdf_pdf(mp, normal, outgoing, incoming) + 0.5f * lights_pdf(sc, stack, hit_pos, incoming, eps);
+                p.weight = mul(p.weight, divs(bsdf_eval(mp, normal, outgoing, incoming), prob));
+            }
+            else if (TYPE == LUPIN_PATHTRACE_NAIVE)
+            {
+                float rnl = rnd(p.rng);
+                float ra = rnd(p.rng), rb = rnd(p.rng);
+                incoming = bsdf_sample(mp, normal, outgoing, rnl, ra, rb);
+                if (is_zero3(incoming)) return false;
+                p.weight = mul(p.weight, divs(bsdf_eval(mp, normal, outgoing, incoming), bsdf_pdf(mp, normal, outgoing, incoming)));
+            }
+            else   // MIS: BSDF sample then light sample, power heuristic (:802-855)
+            {
+                for (int k = 0; k < 2; k++)
+                {
+                    const bool light_turn = (k != 0);
+                    f3 mi;
+                    if (light_turn) mi = lights_sample(sc, hit_pos, p.rng);
+                    else
+                    {
+                        float rnl = rnd(p.rng);
+                        float ra = rnd(p.rng), rb = rnd(p.rng);
+                        mi = bsdf_sample(mp, normal, outgoing, rnl, ra, rb);
+                    }
+                    if (is_zero3(mi)) break;
+                    if (!light_turn) incoming = mi;
+
+                    f3 bsdfcos = bsdf_eval(mp, normal, outgoing, mi);
+                    float light_pdf = lights_pdf(sc, stack, hit_pos, mi, eps);
+                    float b_pdf = bsdf_pdf(mp, normal, outgoing, mi);
+                    float mis_w;
+                    if (light_turn) mis_w = (light_pdf * light_pdf) / (light_pdf * light_pdf + b_pdf * b_pdf) / light_pdf;
+                    else            mis_w = (b_pdf * b_pdf) / (b_pdf * b_pdf + light_pdf * light_pdf) / b_pdf;
+
+                    if (none_zero3(bsdfcos) && mis_w != 0.0f)
+                    {
+                        Closest mc = scene_closest(sc, stack, hit_pos, mi, eps);
+                        const bool mhit = mc.t != LP_F32_MAX;
+                        if (!light_turn)
+                        {
+                            pb.next_hit[slot] = make_float4(mhit ? mc.t : 0.0f, mhit ? mc.u : 0.0f, mhit ? mc.v : 0.0f,
+                                                            __uint_as_float(mhit ? mc.inst : HIT_MISS));
+                            pb.next_tri[slot] = mc.tri;
+                        }
+                        f3 emission;
+                        if (mhit) emission = material_point(sc, resolve_surface(sc, mc.inst, mc.tri, mc.u, mc.v)).emission;
+                        else emission = environment_radiance(sc, mi);
+                        p.radiance = add(p.radiance, scale(mul(mul(p.weight, bsdfcos), emission), mis_w));
+                    }
+                }
+                p.weight = mul(p.weight, divs(bsdf_eval(mp, normal, outgoing, incoming), bsdf_pdf(mp, normal, outgoing, incoming)));
+                p.next_emission = false;
+            }
+        }
+        else
+        {
+            incoming = delta_sample(mp, normal, outgoing, rnd(p.rng));
+            if (is_zero3(incoming)) return false;
+            p.weight = mul(p.weight, divs(delta_eval(mp, normal, outgoing, incoming), delta_pdf(mp, normal, outgoing, incoming)));
+            if (TYPE == LUPIN_PATHTRACE_MIS) p.next_emission = true;
+        }
+
+        // volume stack: push when empty, otherwise pop (:667-681) -- depth never exceeds 1
+        if (mat_is_volumetric(mp) && dot3(normal, outgoing) * dot3(normal, incoming) < 0.0f)
+        {
+            if (!p.in_medium)
+            {
+                p.medium.density = mp.density;
+                p.medium.scattering = mp.scattering;
+                p.medium.anisotropy = mp.anisotropy;
+                p.in_medium = true;
+            }
+            else p.in_medium = false;
+        }
+    }
+    else
+    {
+        hit_pos = add(p.ori, scale(p.dir, volume_dst));
+        if (TYPE == LUPIN_PATHTRACE_NAIVE)
+        {
+            float unused0 = rnd(p.rng); (void)unused0;
+            float ra = rnd(p.rng), rb = rnd(p.rng);
+            incoming = phase_sample(p.medium, outgoing, ra, rb);
+            if (is_zero3(incoming)) return false;
+            float prob = phase_pdf(p.medium, outgoing, incoming);
+            p.weight = mul(p.weight, divs(phase_eval(p.medium, outgoing, incoming), prob));
+        }
+        else
+        {
+            if (rnd(p.rng) < 0.5f)
+            {
+                float unused0 = rnd(p.rng); (void)unused0;   // rnd0 is drawn and dropped (:700)
+                float ra = rnd(p.rng), rb = rnd(p.rng);
+                incoming = phase_sample(p.medium, outgoing, ra, rb);
+            }
+            else incoming = lights_sample(sc, hit_pos, p.rng);
+            if (TYPE == LUPIN_PATHTRACE_MIS) p.next_emission = true;
+            if (is_zero3(incoming)) return false;
+            float prob = 0.5f * phase_pdf(p.medium, outgoing, incoming) + 0.5f * lights_pdf(sc, stack, hit_pos, incoming, eps);
+            p.weight = mul(p.weight, divs(phase_eval(p.medium, outgoing, incoming), prob));
+        }
+    }
+
+    p.ori = hit_pos;
+    p.dir = incoming;
+
+    // weight check and Russian roulette (:720-729)
+    if (is_zero3(p.weight) || !finite3(p.weight)) return false;
+    if (p.bounce > 3)
+    {
+        float survive = minf(0.99f, maxf(p.weight.x, maxf(p.weight.y, p.weight.z)));
+        if (rnd(p.rng) >= survive) return false;
+        p.weight = scale(p.weight, 1.0f / survive);
+    }
+    return true;
+}
+
+template <int TYPE>
+__global__ void __launch_bounds__(LP_BLOCK) k_shade(SceneDev sc, FrameParams fp, PathBuffers pb, uint32_t iter,
+                                                    unsigned long long *path_counter)
+{
+    extern __shared__ uint32_t lds_stack[];
+    const uint32_t count = pb.counts[iter];
+    const uint32_t i = blockIdx.x * LP_BLOCK + threadIdx.x;
+    bool alive = false;
+    uint32_t slot = 0;
+    if (i < count)
+    {
+        slot = pb.queue[iter & 1][i];
+        float4 orr = pb.ori_rng[slot];
+        float4 dm = pb.dir_meta[slot];
+        float4 w4 = pb.weight[slot];
+        float4 r4 = pb.radiance[slot];
+        uint32_t meta = __float_as_uint(dm.w);
+
+        PathRegs p;
+        p.ori = mk3(orr.x, orr.y, orr.z);
+        p.dir = mk3(dm.x, dm.y, dm.z);
+        p.weight = mk3(w4.x, w4.y, w4.z);
+        p.radiance = mk3(r4.x, r4.y, r4.z);
+        p.rng = __float_as_uint(orr.w);
+        p.bounce = (int)(meta & META_BOUNCE_MASK);
+        p.in_medium = (meta & META_VOLUME) != 0;
+        p.next_emission = (meta & META_NEXT_EMISSION) != 0;
+        uint32_t sample = meta >> META_SAMPLE_SHIFT;
+        const bool was_in_medium = p.in_medium;
+        if (p.in_medium)
+        {
+            float4 a = pb.vol0[slot], b = pb.vol1[slot];
+            p.medium.density = mk3(a.x, a.y, a.z);
+            p.medium.anisotropy = a.w;
+            p.medium.scattering = mk3(b.x, b.y, b.z);
+        }
+        else { p.medium.density = splat(0.0f); p.medium.scattering = splat(0.0f); p.medium.anisotropy = 0.0f; }
+
+        bool cont = integrate_vertex<TYPE>(sc, lds_stack, fp, p, pb.hit[slot], pb.hit_tri[slot], pb, slot);
+        if (cont)
+        {
+            p.bounce++;
+            if (p.bounce > (int)fp.max_bounces) cont = false;   // loop condition `bounce <= MAX_BOUNCES` (:596)
+        }
+
+        if (cont)
+        {
+            alive = true;
+            if (p.in_medium && !was_in_medium)
+            {
+                pb.vol0[slot] = make_float4(p.medium.density.x, p.medium.density.y, p.medium.density.z, p.medium.anisotropy);
+                pb.vol1[slot] = make_float4(p.medium.scattering.x, p.medium.scattering.y, p.medium.scattering.z, 0.0f);
+            }
+            pb.weight[slot] = make_float4(p.weight.x, p.weight.y, p.weight.z, 0.0f);
+            pb.radiance[slot] = make_float4(p.radiance.x, p.radiance.y, p.radiance.z, 0.0f);
+        }
+        else
+        {
+            // path finished: fold its radiance into the pixel, start the pixel's next sample (:234-239)
+            float4 c4 = pb.color[slot];
+            f3 cr = clamp_radiance(p.radiance, fp.pc.max_radiance);
+            pb.color[slot] = make_float4(c4.x + cr.x, c4.y + cr.y, c4.z + cr.z, 0.0f);
+            sample++;
+            if (sample < fp.spp)
+            {
+                alive = true;
+                uint32_t gx, gy;
+                slot_to_pixel(fp, slot, gx, gy);
+                camera_ray(fp, gx, gy, p.rng, p.ori, p.dir);
+                p.bounce = 0;
+                p.in_medium = false;
+                p.next_emission = true;
+                pb.weight[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+                pb.radiance[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (TYPE == LUPIN_PATHTRACE_MIS)
+                {
+                    pb.next_hit[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(HIT_MISS));
+                    pb.next_tri[slot] = 0u;
+                }
+            }
+        }
+        if (alive)
+        {
+            uint32_t nm = ((uint32_t)p.bounce & META_BOUNCE_MASK) | (p.in_medium ? META_VOLUME : 0u) |
+                          (p.next_emission ? META_NEXT_EMISSION : 0u) | (sample << META_SAMPLE_SHIFT);
+            pb.ori_rng[slot] = make_float4(p.ori.x, p.ori.y, p.ori.z, __uint_as_float(p.rng));
+            pb.dir_meta[slot] = make_float4(p.dir.x, p.dir.y, p.dir.z, __uint_as_float(nm));
+        }
+    }
+    if (i == 0 && iter == 0 && path_counter) atomicAdd(path_counter, (unsigned long long)count * fp.spp);
+
+    // append survivors to the next queue: one atomic per wave
+    const unsigned long long mask = __ballot(alive);
+    if (mask)
+    {
+        const int lane = threadIdx.x & 63;
+        const int leader = __ffsll((long long)mask) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&pb.counts[iter + 1], (uint32_t)__popcll(mask));
+        base = __shfl(base, leader);
+        if (alive) pb.queue[(iter + 1) & 1][base + __popcll(mask & ((1ull << lane) - 1ull))] = slot;
+    }
+}
+
+// pathtrace_main tail (pathtracer.wgsl:275-289)
+__global__ void __launch_bounds__(LP_BLOCK) k_resolve(FrameParams fp, PathBuffers pb, uint32_t n,
+                                                      const __half *prev, __half *out)
+{
+    uint32_t slot = blockIdx.x * LP_BLOCK + threadIdx.x;
+    if (slot >= n) return;
+    uint32_t gx, gy;
+    slot_to_pixel(fp, slot, gx, gy);
+    float4 c4 = pb.color[slot];
+    float spp = (float)fp.spp;
+    f3 c = mk3(maxf(c4.x / spp, 0.0f), maxf(c4.y / spp, 0.0f), maxf(c4.z / spp, 0.0f));
+    size_t px = ((size_t)gy * fp.width + gx) * 4;
+    if (fp.pc.accum_counter != 0)
+    {
+        float w = 1.0f / (float)fp.pc.accum_counter;
+        f3 pc = mk3(__half2float(prev[px + 0]), __half2float(prev[px + 1]), __half2float(prev[px + 2]));
+        c = mk3(maxf(pc.x * (1.0f - w) + c.x * w, 0.0f), maxf(pc.y * (1.0f - w) + c.y * w, 0.0f), maxf(pc.z * (1.0f - w) + c.z * w, 0.0f));
+    }
+    out[px + 0] = __float2half_rn(c.x);
+    out[px + 1] = __float2half_rn(c.y);
+    out[px + 2] = __float2half_rn(c.z);
+    out[px + 3] = __float2half_rn(1.0f);
+}
+
+// standalone closest-hit probe (bvh_custom.wgsl:7-110)
+__global__ void __launch_bounds__(LP_BLOCK) k_trace(SceneDev sc, uint32_t n, const float *ori, const float *dir, float eps,
+                                                    uint32_t *out_hit, float *out_dst, float *out_uv, uint32_t *out_inst, uint32_t *out_tri)
+{
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t i = blockIdx.x * LP_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    f3 o = mk3(ori[i * 3 + 0], ori[i * 3 + 1], ori[i * 3 + 2]);
+    f3 d = mk3(dir[i * 3 + 0], dir[i * 3 + 1], dir[i * 3 + 2]);
+    Closest c = scene_closest(sc, lds_stack, o, d, eps);
+    bool hit = c.t != LP_F32_MAX;
+    out_hit[i] = hit ? 1u : 0u;
+    out_dst[i] = hit ? c.t : 0.0f;
+    out_uv[i * 2 + 0] = hit ? c.u : 0.0f;
+    out_uv[i * 2 + 1] = hit ? c.v : 0.0f;
+    out_inst[i] = hit ? c.inst : 0u;
+    out_tri[i] = hit ? (c.tri - sc.meshes[sc.instances[c.inst].mesh_idx].tri_offset) : 0u;
+}
+
+// tile pack / unpack for the multi-GPU gather: tiles t = rank, rank+world, ... in row-major tile order
+__global__ void __launch_bounds__(LP_BLOCK) k_pack_tiles(const uint2 *tex, uint2 *packed, uint32_t width, uint32_t height,
+                                                         uint32_t tile_px, uint32_t rank, uint32_t world, int unpack)
+{
+    uint32_t ntx = (width - 1) / tile_px + 1;
+    uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t y = blockIdx.y;
+    if (x >= width || y >= height) return;
+    uint32_t tx = x / tile_px, ty = y / tile_px;
+    uint32_t t = ty * ntx + tx;
+    if (t % world != rank) return;
+    // pixels in owned tiles before tile t
+    unsigned long long before = 0;
+    uint32_t nty = (height - 1) / tile_px + 1;
+    (void)nty;
+    // full rows of tiles above: count owned tiles per row analytically would need care at edges;
+    // tiles are few (<= a few thousand), a loop is fine.
+    for (uint32_t q = rank; q < t; q += world)
+    {
+        uint32_t qx = (q % ntx) * tile_px, qy = (q / ntx) * tile_px;
+        uint32_t w = min(tile_px, width - qx), h = min(tile_px, height - qy);
+        before += (unsigned long long)w * h;
+    }
+    uint32_t ox = tx * tile_px, oy = ty * tile_px;
+    uint32_t w = min(tile_px, width - ox);
+    unsigned long long pi = before + (unsigned long long)(y - oy) * w + (x - ox);
+    if (unpack) const_cast<uint2 *>(tex)[(size_t)y * width + x] = packed[pi];
+    else packed[pi] = tex[(size_t)y * width + x];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host side
+// ------------------------------------------------------------------------------------------------
+
+static inline float host_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+static thread_local std::string g_last_error;
+static int fail(int code, const std::string &msg) { g_last_error = msg; return code; }
+#define HIP_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return fail(LUPIN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } while (0)
+
+struct LupinContext
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    PathBuffers pb{};
+    uint64_t capacity = 0;          // slots the path buffers hold
+    uint32_t counts_capacity = 0;
+    unsigned long long *stat_counters = nullptr;   // [0] path bounces, [1] paths
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_extend, ev_shade, ev_total;
+    std::vector<hipEvent_t> ev_pool;
+    uint64_t extend_launches = 0;
+};
+
+struct LupinPathtraceResources
+{
+    LupinContext *ctx;
+    LupinBakedPathtraceParams params;
+};
+
+struct LupinTexture
+{
+    LupinContext *ctx;
+    uint32_t width, height;
+    __half *data;
+};
+
+struct LupinDoubleBufferedTexture
+{
+    LupinContext *ctx;
+    LupinTexture *tex[2];
+    int front_idx, back_idx;
+};
+
+struct LupinScene
+{
+    LupinContext *ctx;
+    SceneDev dev{};
+    std::vector<void *> allocations;
+    uint32_t stack_entries = 1;
+    bool has_sw_bvh = false;
+    bool envs_empty = true, lights_empty = true, instances_empty = true;
+};
+
+template <typename T>
+static int upload(LupinScene *sc, const std::vector<T> &host, const T **out)
+{
+    *out = nullptr;
+    size_t bytes = std::max<size_t>(host.size() * sizeof(T), sizeof(T) > 16 ? sizeof(T) : 16);
+    void *d = nullptr;
+    HIP_TRY(hipMalloc(&d, bytes));
+    sc->allocations.push_back(d);
+    HIP_TRY(hipMemsetAsync(d, 0, bytes, sc->ctx->stream));
+    if (!host.empty()) HIP_TRY(hipMemcpyAsync(d, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, sc->ctx->stream));
+    *out = reinterpret_cast<const T *>(d);
+    return LUPIN_OK;
+}
+
+static hipEvent_t get_event(LupinContext *ctx)
+{
+    if (!ctx->ev_pool.empty()) { hipEvent_t e = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+
+static int ensure_path_buffers(LupinContext *ctx, uint64_t slots, uint32_t iterations)
+{
+    if (slots > ctx->capacity)
+    {
+        PathBuffers &pb = ctx->pb;
+        void **ptrs[] = {(void **)&pb.ori_rng, (void **)&pb.dir_meta, (void **)&pb.weight, (void **)&pb.radiance, (void **)&pb.color,
+                         (void **)&pb.hit, (void **)&pb.hit_tri, (void **)&pb.vol0, (void **)&pb.vol1, (void **)&pb.next_hit,
+                         (void **)&pb.next_tri, (void **)&pb.queue[0], (void **)&pb.queue[1]};
+        size_t elem[] = {16, 16, 16, 16, 16, 16, 4, 16, 16, 16, 4, 4, 4};
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (int k = 0; k < 13; k++)
+        {
+            if (*ptrs[k]) { hipFree(*ptrs[k]); *ptrs[k] = nullptr; }
+            HIP_TRY(hipMalloc(ptrs[k], (size_t)slots * elem[k]));
+        }
+        ctx->capacity = slots;
+    }
+    if (iterations + 2 > ctx->counts_capacity)
+    {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->pb.counts) hipFree(ctx->pb.counts);
+        ctx->pb.counts = nullptr;
+        HIP_TRY(hipMalloc((void **)&ctx->pb.counts, (size_t)(iterations + 2) * sizeof(uint32_t)));
+        ctx->counts_capacity = iterations + 2;
+    }
+    return LUPIN_OK;
+}
+
+// depth of a hierarchy in internal levels = worst-case number of parked far children
+static uint32_t blas_depth(const LupinBvhNode *nodes, uint32_t count)
+{
+    if (count == 0) return 0;
+    uint32_t best = 0;
+    std::vector<std::pair<uint32_t, uint32_t>> st;
+    st.push_back({0u, 0u});
+    while (!st.empty())
+    {
+        auto [n, d] = st.back();
+        st.pop_back();
+        if (nodes[n].tri_count == 0)
+        {
+            best = std::max(best, d + 1);
+            st.push_back({nodes[n].tri_begin_or_first_child, d + 1});
+            st.push_back({nodes[n].tri_begin_or_first_child + 1, d + 1});
+        }
+    }
+    return best;
+}
+
+template <int TYPE>
+static void launch_iteration(LupinContext *ctx, const LupinScene *scene, const FrameParams &fp, uint32_t blocks, size_t lds, uint32_t iter)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    if (ctx->timing) { e0 = get_event(ctx); e1 = get_event(ctx); e2 = get_event(ctx); hipEventRecord(e0, ctx->stream); }
+    hipLaunchKernelGGL(k_extend<TYPE>, dim3(blocks), dim3(LP_BLOCK), lds, ctx->stream, scene->dev, fp, ctx->pb, iter, ctx->stat_counters + 0);
+    if (ctx->timing) hipEventRecord(e1, ctx->stream);
+    hipLaunchKernelGGL(k_shade<TYPE>, dim3(blocks), dim3(LP_BLOCK), lds, ctx->stream, scene->dev, fp, ctx->pb, iter, ctx->stat_counters + 1);
+    if (ctx->timing)
+    {
+        hipEventRecord(e2, ctx->stream);
+        ctx->ev_extend.push_back({e0, e1});
+        ctx->ev_shade.push_back({e1, e2});
+    }
+    ctx->extend_launches++;
+}
+
+extern "C" {
+
+const char *lupin_hip_last_error(void) { return g_last_error.c_str(); }
+
+int lupin_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
+{
+    if (!out_ctx) return fail(LUPIN_ERR_INVALID_ARGUMENT, "out_ctx is null");
+    int n = lupin_hip_device_count();
+    if (n <= 0) return fail(LUPIN_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
+    if (device_ordinal < 0 || device_ordinal >= n) return fail(LUPIN_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device_ordinal));
+    LupinContext *ctx = new LupinContext();
+    ctx->device = device_ordinal;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ctx; return fail(LUPIN_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    e = hipMalloc((void **)&ctx->stat_counters, 2 * sizeof(unsigned long long));
+    if (e != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return fail(LUPIN_ERR_HIP, "hipMalloc(stat counters)"); }
+    hipMemsetAsync(ctx->stat_counters, 0, 2 * sizeof(unsigned long long), ctx->stream);
+    *out_ctx = ctx;
+    return LUPIN_OK;
+}
+
+void lupin_hip_destroy_context(LupinContext *ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    PathBuffers &pb = ctx->pb;
+    void *ptrs[] = {pb.ori_rng, pb.dir_meta, pb.weight, pb.radiance, pb.color, pb.hit, pb.hit_tri, pb.vol0, pb.vol1,
+                    pb.next_hit, pb.next_tri, pb.queue[0], pb.queue[1], pb.counts, ctx->stat_counters};
+    for (void *p : ptrs) if (p) hipFree(p);
+    for (auto &pr : ctx->ev_extend) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (auto &pr : ctx->ev_shade) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (auto &pr : ctx->ev_total) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (auto e : ctx->ev_pool) hipEventDestroy(e);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int lupin_hip_sync(LupinContext *ctx)
+{
+    if (!ctx) return fail(LUPIN_ERR_INVALID_ARGUMENT, "ctx is null");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return LUPIN_OK;
+}
+
+int lupin_hip_build_pathtrace_resources(LupinContext *ctx, const LupinBakedPathtraceParams *params, LupinPathtraceResources **out_res)
+{
+    if (!ctx || !params || !out_res) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
+    if (params->samples_per_pixel == 0 || params->samples_per_pixel > 0xFFFFu) return fail(LUPIN_ERR_INVALID_ARGUMENT, "samples_per_pixel must be in [1, 65535]");
+    if (params->max_bounces >= META_BOUNCE_MASK) return fail(LUPIN_ERR_INVALID_ARGUMENT, "max_bounces must be < 4095");
+    LupinPathtraceResources *r = new LupinPathtraceResources();
+    r->ctx = ctx;
+    r->params = *params;
+    *out_res = r;
+    return LUPIN_OK;
+}
+void lupin_hip_destroy_pathtrace_resources(LupinPathtraceResources *res) { delete res; }
+
+// ---- scene upload ----
+
+int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinScene **out_scene)
+{
+    if (!ctx || !desc || !out_scene) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const LupinSceneDesc &s = *desc;
+
+    // ---- validation (validate_scene, data_structures.rs:876-928, plus what the kernels index) ----
+    for (uint32_t i = 0; i < s.num_instances; i++)
+    {
+        if (s.instances[i].mesh_idx >= s.num_meshes) return fail(LUPIN_ERR_INVALID_ARGUMENT, "instance mesh_idx out of range");
+        if (s.instances[i].mat_idx >= s.num_materials) return fail(LUPIN_ERR_INVALID_ARGUMENT, "instance mat_idx out of range");
+    }
+    auto tex_ok = [&](uint32_t t) { return t == LUPIN_SENTINEL_IDX || t < s.num_textures; };
+    for (uint32_t i = 0; i < s.num_materials; i++)
+    {
+        const LupinMaterial &m = s.materials[i];
+        if (!tex_ok(m.color_tex_idx) || !tex_ok(m.emission_tex_idx) || !tex_ok(m.roughness_tex_idx) || !tex_ok(m.scattering_tex_idx) || !tex_ok(m.normal_tex_idx))
+            return fail(LUPIN_ERR_INVALID_ARGUMENT, "material texture index out of range");
+    }
+    if (s.num_environments > LUPIN_MAX_ENVS) return fail(LUPIN_ERR_INVALID_ARGUMENT, "too many environments");
+    for (uint32_t i = 0; i < s.num_environments; i++)
+    {
+        const LupinEnvironment &e = s.environments[i];
+        if (!tex_ok(e.emission_tex_idx)) return fail(LUPIN_ERR_INVALID_ARGUMENT, "environment texture index out of range");
+        if (e.emission_tex_idx != LUPIN_SENTINEL_IDX)
+        {
+            const LupinTextureDesc &t = s.textures[e.emission_tex_idx];
+            if (!s.env_alias_tables || s.env_alias_tables[i].num_bins != t.width * t.height)
+                return fail(LUPIN_ERR_INVALID_ARGUMENT, "environment alias table must have one bin per texel");
+        }
+    }
+    for (uint32_t i = 0; i < s.num_lights; i++)
+    {
+        if (s.lights[i].instance_idx >= s.num_instances) return fail(LUPIN_ERR_INVALID_ARGUMENT, "light instance_idx out of range");
+        if (!s.alias_tables || s.alias_tables[i].num_bins == 0) return fail(LUPIN_ERR_INVALID_ARGUMENT, "light without alias table");
+        uint32_t mesh = s.instances[s.lights[i].instance_idx].mesh_idx;
+        if (s.alias_tables[i].num_bins != s.meshes[mesh].num_indices / 3) return fail(LUPIN_ERR_INVALID_ARGUMENT, "light alias table size != triangle count");
+    }
+    for (uint32_t i = 0; i < s.num_textures; i++)
+        if (s.textures[i].width == 0 || s.textures[i].height == 0 || !s.textures[i].pixels || s.textures[i].format > LUPIN_TEX_RGBA16_FLOAT)
+            return fail(LUPIN_ERR_INVALID_ARGUMENT, "bad texture descriptor");
+
+    LupinScene *sc = new LupinScene();
+    sc->ctx = ctx;
+    sc->instances_empty = s.num_instances == 0;
+    sc->lights_empty = s.num_lights == 0;
+    sc->envs_empty = s.num_environments == 0;
+    sc->has_sw_bvh = s.num_tlas_nodes > 0 || s.num_instances == 0;
+    if (s.num_instances > 0 && s.num_tlas_nodes == 0) { delete sc; return fail(LUPIN_ERR_NO_SW_BVH, "scene has instances but no TLAS (software BVH required)"); }
+
+    // ---- vertex attribute pools ----
+    std::vector<uint32_t> normal_base(s.num_normal_buffers), uv_base(s.num_texcoord_buffers), color_base(s.num_color_buffers);
+    std::vector<float4> normals;
+    std::vector<float2> texcoords;
+    std::vector<float4> colors;
+    for (uint32_t b = 0; b < s.num_normal_buffers; b++)
+    {
+        normal_base[b] = (uint32_t)normals.size();
+        for (uint32_t v = 0; v < s.verts_normal_array[b].num_verts; v++) { const float *p = s.verts_normal_array[b].data + (size_t)v * 4; normals.push_back(make_float4(p[0], p[1], p[2], 0.0f)); }
+    }
+    for (uint32_t b = 0; b < s.num_texcoord_buffers; b++)
+    {
+        uv_base[b] = (uint32_t)texcoords.size();
+        for (uint32_t v = 0; v < s.verts_texcoord_array[b].num_verts; v++) { const float *p = s.verts_texcoord_array[b].data + (size_t)v * 2; texcoords.push_back(make_float2(p[0], p[1])); }
+    }
+    for (uint32_t b = 0; b < s.num_color_buffers; b++)
+    {
+        color_base[b] = (uint32_t)colors.size();
+        for (uint32_t v = 0; v < s.verts_color_array[b].num_verts; v++) { const float *p = s.verts_color_array[b].data + (size_t)v * 4; colors.push_back(make_float4(p[0], p[1], p[2], p[3])); }
+    }
+
+    // ---- meshes: triangles in leaf order, BLAS as 64-byte child-pair nodes ----
+    std::vector<TriVerts> tris;
+    std::vector<uint32_t> tri_indices;
+    std::vector<WideNode> blas;
+    std::vector<MeshDev> meshes(s.num_meshes);
+    std::vector<uint32_t> mesh_root(s.num_meshes);
+    uint32_t max_blas_depth = 0;
+    for (uint32_t mi = 0; mi < s.num_meshes; mi++)
+    {
+        const LupinMeshDesc &m = s.meshes[mi];
+        const LupinMeshInfo &info = s.mesh_infos[mi];
+        MeshDev md;
+        md.tri_offset = (uint32_t)tris.size();
+        auto attr_base = [&](uint32_t idx, const std::vector<uint32_t> &bases, uint32_t nbuf, const LupinVertexBufferDesc *bufs, bool &ok) -> uint32_t {
+            if (idx == LUPIN_SENTINEL_IDX) return LUPIN_SENTINEL_IDX;
+            if (idx >= nbuf || bufs[idx].num_verts != m.num_verts) { ok = false; return LUPIN_SENTINEL_IDX; }
+            return bases[idx];
+        };
+        bool ok = true;
+        md.normals_base = attr_base(info.normals_buf_idx, normal_base, s.num_normal_buffers, s.verts_normal_array, ok);
+        md.texcoords_base = attr_base(info.texcoords_buf_idx, uv_base, s.num_texcoord_buffers, s.verts_texcoord_array, ok);
+        md.colors_base = attr_base(info.colors_buf_idx, color_base, s.num_color_buffers, s.verts_color_array, ok);
+        if (!ok) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "mesh attribute buffer index / size mismatch"); }
+        meshes[mi] = md;
+
+        uint32_t ntris = m.num_indices / 3;
+        for (uint32_t i = 0; i < ntris * 3; i++)
+            if (m.indices[i] >= m.num_verts) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "vertex index out of range"); }
+        for (uint32_t t = 0; t < ntris; t++)
+        {
+            TriVerts tv;
+            const float *p0 = m.verts_pos + (size_t)m.indices[t * 3 + 0] * 4;
+            const float *p1 = m.verts_pos + (size_t)m.indices[t * 3 + 1] * 4;
+            const float *p2 = m.verts_pos + (size_t)m.indices[t * 3 + 2] * 4;
+            tv.v0 = make_float4(p0[0], p0[1], p0[2], 0.0f);
+            tv.v1 = make_float4(p1[0], p1[1], p1[2], 0.0f);
+            tv.v2 = make_float4(p2[0], p2[1], p2[2], 0.0f);
+            tris.push_back(tv);
+            tri_indices.push_back(m.indices[t * 3 + 0]);
+            tri_indices.push_back(m.indices[t * 3 + 1]);
+            tri_indices.push_back(m.indices[t * 3 + 2]);
+        }
+        if (ntris == 0 || m.num_bvh_nodes == 0)
+        {
+            // degenerate mesh: one never-hit triangle so that traversal has a well-formed leaf
+            TriVerts tv;
+            tv.v0 = make_float4(0, 0, 0, host_u2f(LEAF_END_BITS));
+            tv.v1 = tv.v2 = make_float4(0, 0, 0, 0);
+            mesh_root[mi] = REF_LEAF | (uint32_t)tris.size();
+            tris.push_back(tv);
+            tri_indices.push_back(0); tri_indices.push_back(0); tri_indices.push_back(0);
+            continue;
+        }
+        // node index -> child reference
+        std::vector<uint32_t> ref(m.num_bvh_nodes);
+        uint32_t wide_base = (uint32_t)blas.size(), wide_count = 0;
+        for (uint32_t n = 0; n < m.num_bvh_nodes; n++)
+        {
+            const LupinBvhNode &nd = m.bvh_nodes[n];
+            if (nd.tri_count > 0)
+            {
+                if ((uint64_t)nd.tri_begin_or_first_child + nd.tri_count > ntris) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "BLAS leaf range out of bounds"); }
+                ref[n] = REF_LEAF | (md.tri_offset + nd.tri_begin_or_first_child);
+                uint32_t last = md.tri_offset + nd.tri_begin_or_first_child + nd.tri_count - 1;
+                tris[last].v0.w = host_u2f(LEAF_END_BITS);
+            }
+            else
+            {
+                if ((uint64_t)nd.tri_begin_or_first_child + 1 >= m.num_bvh_nodes) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "BLAS child index out of bounds"); }
+                ref[n] = wide_base + wide_count++;
+            }
+        }
+        blas.resize(wide_base + wide_count);
+        for (uint32_t n = 0; n < m.num_bvh_nodes; n++)
+        {
+            const LupinBvhNode &nd = m.bvh_nodes[n];
+            if (nd.tri_count > 0) continue;
+            const LupinBvhNode &l = m.bvh_nodes[nd.tri_begin_or_first_child];
+            const LupinBvhNode &r = m.bvh_nodes[nd.tri_begin_or_first_child + 1];
+            WideNode w;
+            w.a = make_float4(l.aabb_min[0], l.aabb_min[1], l.aabb_min[2], l.aabb_max[0]);
+            w.b = make_float4(l.aabb_max[1], l.aabb_max[2], r.aabb_min[0], r.aabb_min[1]);
+            w.c = make_float4(r.aabb_min[2], r.aabb_max[0], r.aabb_max[1], r.aabb_max[2]);
+            w.d = make_uint4(ref[nd.tri_begin_or_first_child], ref[nd.tri_begin_or_first_child + 1], 0u, 0u);
+            blas[ref[n]] = w;
+        }
+        mesh_root[mi] = ref[0];
+        max_blas_depth = std::max(max_blas_depth, blas_depth(m.bvh_nodes, m.num_bvh_nodes));
+    }
+
+    // ---- TLAS ----
+    std::vector<WideNode> tlas;
+    uint32_t tlas_root = REF_LEAF;
+    uint32_t tlas_depth = 0;
+    if (s.num_tlas_nodes > 0)
+    {
+        std::vector<uint32_t> ref(s.num_tlas_nodes);
+        uint32_t wide_count = 0;
+        for (uint32_t n = 0; n < s.num_tlas_nodes; n++)
+        {
+            const LupinTlasNode &nd = s.tlas_nodes[n];
+            if (nd.left == 0)
+            {
+                if (nd.instance_idx >= s.num_instances) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "TLAS leaf instance out of range"); }
+                ref[n] = REF_LEAF | nd.instance_idx;
+            }
+            else
+            {
+                if (nd.left >= s.num_tlas_nodes || nd.right >= s.num_tlas_nodes) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "TLAS child out of range"); }
+                ref[n] = wide_count++;
+            }
+        }
+        tlas.resize(wide_count);
+        for (uint32_t n = 0; n < s.num_tlas_nodes; n++)
+        {
+            const LupinTlasNode &nd = s.tlas_nodes[n];
+            if (nd.left == 0) continue;
+            const LupinTlasNode &l = s.tlas_nodes[nd.left];
+            const LupinTlasNode &r = s.tlas_nodes[nd.right];
+            WideNode w;
+            w.a = make_float4(l.aabb_min[0], l.aabb_min[1], l.aabb_min[2], l.aabb_max[0]);
+            w.b = make_float4(l.aabb_max[1], l.aabb_max[2], r.aabb_min[0], r.aabb_min[1]);
+            w.c = make_float4(r.aabb_min[2], r.aabb_max[0], r.aabb_max[1], r.aabb_max[2]);
+            w.d = make_uint4(ref[nd.left], ref[nd.right], 0u, 0u);
+            tlas[ref[n]] = w;
+        }
+        tlas_root = ref[0];
+        // depth from the root (bounded walk: a malformed cyclic TLAS is rejected)
+        std::vector<std::pair<uint32_t, uint32_t>> st;
+        st.push_back({0u, 0u});
+        uint64_t visited = 0;
+        while (!st.empty())
+        {
+            auto [n, d] = st.back();
+            st.pop_back();
+            if (++visited > (uint64_t)s.num_tlas_nodes * 2 + 2) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "TLAS is not a tree"); }
+            if (s.tlas_nodes[n].left != 0)
+            {
+                tlas_depth = std::max(tlas_depth, d + 1);
+                st.push_back({s.tlas_nodes[n].left, d + 1});
+                st.push_back({s.tlas_nodes[n].right, d + 1});
+            }
+        }
+    }
+    sc->stack_entries = tlas_depth + max_blas_depth + 1;
+
+    // ---- instances ----
+    std::vector<InstanceDev> instances(s.num_instances);
+    for (uint32_t i = 0; i < s.num_instances; i++)
+    {
+        const LupinInstance &in = s.instances[i];
+        const float (*m)[4] = in.transpose_inverse_transform.m;
+        InstanceDev d;
+        d.r0 = make_float4(m[0][0], m[0][1], m[0][2], m[0][3]);
+        d.r1 = make_float4(m[1][0], m[1][1], m[1][2], m[1][3]);
+        d.r2 = make_float4(m[2][0], m[2][1], m[2][2], m[2][3]);
+        d.blas_root = mesh_root[in.mesh_idx];
+        d.mat_idx = in.mat_idx;
+        d.mesh_idx = in.mesh_idx;
+        const LupinMaterial &mat = s.materials[in.mat_idx];
+        bool maybe_alpha = !(mat.color[3] == 1.0f) ||
+                           (mat.color_tex_idx != LUPIN_SENTINEL_IDX && meshes[in.mesh_idx].texcoords_base != LUPIN_SENTINEL_IDX) ||
+                           meshes[in.mesh_idx].colors_base != LUPIN_SENTINEL_IDX;
+        d.flags = maybe_alpha ? 1u : 0u;
+        instances[i] = d;
+    }
+
+    // ---- textures ----
+    std::vector<TextureDev> textures(s.num_textures);
+    std::vector<uint8_t> texels;
+    for (uint32_t i = 0; i < s.num_textures; i++)
+    {
+        const LupinTextureDesc &t = s.textures[i];
+        size_t bpp = (t.format == LUPIN_TEX_RGBA8_UNORM) ? 4 : 8;
+        size_t bytes = (size_t)t.width * t.height * bpp;
+        size_t off = (texels.size() + 15) & ~(size_t)15;
+        texels.resize(off + bytes);
+        memcpy(texels.data() + off, t.pixels, bytes);
+        textures[i].offset = off;
+        textures[i].width = t.width;
+        textures[i].height = t.height;
+        textures[i].format = t.format;
+        textures[i].pad = 0;
+    }
+
+    // ---- lights ----
+    std::vector<AliasRange> alias_ranges(s.num_lights), env_alias_ranges(s.num_environments);
+    std::vector<LupinAliasBin> alias_bins;
+    for (uint32_t i = 0; i < s.num_lights; i++)
+    {
+        alias_ranges[i] = {(uint32_t)alias_bins.size(), s.alias_tables[i].num_bins};
+        alias_bins.insert(alias_bins.end(), s.alias_tables[i].bins, s.alias_tables[i].bins + s.alias_tables[i].num_bins);
+    }
+    for (uint32_t i = 0; i < s.num_environments; i++)
+    {
+        uint32_t nb = s.env_alias_tables ? s.env_alias_tables[i].num_bins : 0;
+        env_alias_ranges[i] = {(uint32_t)alias_bins.size(), nb};
+        if (nb) alias_bins.insert(alias_bins.end(), s.env_alias_tables[i].bins, s.env_alias_tables[i].bins + nb);
+    }
+
+    SceneDev &dv = sc->dev;
+    int rc = LUPIN_OK;
+    std::vector<LupinMaterial> materials(s.materials, s.materials + s.num_materials);
+    std::vector<LupinEnvironment> envs(s.environments, s.environments + s.num_environments);
+    std::vector<LupinLight> lights(s.lights, s.lights + s.num_lights);
+    if ((rc = upload(sc, tlas, &dv.tlas)) || (rc = upload(sc, blas, &dv.blas)) || (rc = upload(sc, tris, &dv.tris)) ||
+        (rc = upload(sc, tri_indices, &dv.tri_indices)) || (rc = upload(sc, instances, &dv.instances)) ||
+        (rc = upload(sc, meshes, &dv.meshes)) || (rc = upload(sc, materials, &dv.materials)) ||
+        (rc = upload(sc, normals, &dv.normals)) || (rc = upload(sc, texcoords, &dv.texcoords)) || (rc = upload(sc, colors, &dv.colors)) ||
+        (rc = upload(sc, textures, &dv.textures)) || (rc = upload(sc, texels, &dv.texels)) ||
+        (rc = upload(sc, envs, &dv.environments)) || (rc = upload(sc, lights, &dv.lights)) ||
+        (rc = upload(sc, alias_ranges, &dv.alias_ranges)) || (rc = upload(sc, env_alias_ranges, &dv.env_alias_ranges)) ||
+        (rc = upload(sc, alias_bins, &dv.alias_bins)))
+    {
+        lupin_hip_scene_destroy(sc);
+        return rc;
+    }
+    dv.tlas_root = tlas_root;
+    dv.num_lights = s.num_lights;
+    dv.num_envs = s.num_environments;
+    dv.num_instances = s.num_instances;
+    hipError_t e = hipStreamSynchronize(ctx->stream);   // host vectors go out of scope
+    if (e != hipSuccess) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_HIP, hipGetErrorString(e)); }
+    *out_scene = sc;
+    return LUPIN_OK;
+}
+
+void lupin_hip_scene_destroy(LupinScene *scene)
+{
+    if (!scene) return;
+    hipSetDevice(scene->ctx->device);
+    hipStreamSynchronize(scene->ctx->stream);
+    for (void *p : scene->allocations) hipFree(p);
+    delete scene;
+}
+
+// ---- textures / double buffering ----
+
+int lupin_hip_texture_create(LupinContext *ctx, uint32_t width, uint32_t height, LupinTexture **out_tex)
+{
+    if (!ctx || !out_tex || width == 0 || height == 0) return fail(LUPIN_ERR_INVALID_ARGUMENT, "bad texture size");
+    HIP_TRY(hipSetDevice(ctx->device));
+    LupinTexture *t = new LupinTexture();
+    t->ctx = ctx; t->width = width; t->height = height; t->data = nullptr;
+    size_t bytes = (size_t)width * height * 4 * sizeof(__half);
+    hipError_t e = hipMalloc((void **)&t->data, bytes);
+    if (e != hipSuccess) { delete t; return fail(LUPIN_ERR_OUT_OF_MEMORY, hipGetErrorString(e)); }
+    hipMemsetAsync(t->data, 0, bytes, ctx->stream);
+    *out_tex = t;
+    return LUPIN_OK;
+}
+void lupin_hip_texture_destroy(LupinTexture *tex)
+{
+    if (!tex) return;
+    hipSetDevice(tex->ctx->device);
+    hipStreamSynchronize(tex->ctx->stream);
+    hipFree(tex->data);
+    delete tex;
+}
+uint32_t lupin_hip_texture_width(const LupinTexture *tex) { return tex ? tex->width : 0; }
+uint32_t lupin_hip_texture_height(const LupinTexture *tex) { return tex ? tex->height : 0; }
+void *lupin_hip_texture_device_ptr(const LupinTexture *tex) { return tex ? (void *)tex->data : nullptr; }
+
+int lupin_hip_texture_upload_rgba16f(LupinTexture *tex, const uint16_t *pixels)
+{
+    if (!tex || !pixels) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(tex->ctx->device));
+    HIP_TRY(hipMemcpyAsync(tex->data, pixels, (size_t)tex->width * tex->height * 8, hipMemcpyHostToDevice, tex->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(tex->ctx->stream));
+    return LUPIN_OK;
+}
+int lupin_hip_texture_download_rgba16f(const LupinTexture *tex, uint16_t *out_pixels)
+{
+    if (!tex || !out_pixels) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(tex->ctx->device));
+    HIP_TRY(hipMemcpyAsync(out_pixels, tex->data, (size_t)tex->width * tex->height * 8, hipMemcpyDeviceToHost, tex->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(tex->ctx->stream));
+    return LUPIN_OK;
+}
+
+int lupin_hip_dbuf_create(LupinContext *ctx, uint32_t width, uint32_t height, LupinDoubleBufferedTexture **out)
+{
+    if (!out) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
+    LupinDoubleBufferedTexture *d = new LupinDoubleBufferedTexture();
+    d->ctx = ctx; d->tex[0] = d->tex[1] = nullptr; d->front_idx = 1; d->back_idx = 0;   // wgpu_utils.rs:293-298
+    int rc = lupin_hip_texture_create(ctx, width, height, &d->tex[0]);
+    if (rc == LUPIN_OK) rc = lupin_hip_texture_create(ctx, width, height, &d->tex[1]);
+    if (rc != LUPIN_OK) { lupin_hip_texture_destroy(d->tex[0]); delete d; return rc; }
+    *out = d;
+    return LUPIN_OK;
+}
+void lupin_hip_dbuf_destroy(LupinDoubleBufferedTexture *t)
+{
+    if (!t) return;
+    lupin_hip_texture_destroy(t->tex[0]);
+    lupin_hip_texture_destroy(t->tex[1]);
+    delete t;
+}
+LupinTexture *lupin_hip_dbuf_front(LupinDoubleBufferedTexture *t) { return t ? t->tex[t->front_idx] : nullptr; }
+LupinTexture *lupin_hip_dbuf_back(LupinDoubleBufferedTexture *t) { return t ? t->tex[t->back_idx] : nullptr; }
+int lupin_hip_dbuf_copy_front_to_back(LupinDoubleBufferedTexture *t)
+{
+    if (!t) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
+    LupinTexture *f = t->tex[t->front_idx], *b = t->tex[t->back_idx];
+    HIP_TRY(hipSetDevice(t->ctx->device));
+    HIP_TRY(hipMemcpyAsync(b->data, f->data, (size_t)f->width * f->height * 8, hipMemcpyDeviceToDevice, t->ctx->stream));
+    return LUPIN_OK;
+}
+void lupin_hip_dbuf_flip(LupinDoubleBufferedTexture *t) { if (t) std::swap(t->front_idx, t->back_idx); }
+int lupin_hip_dbuf_resize(LupinDoubleBufferedTexture *t, uint32_t width, uint32_t height)
+{
+    if (!t) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
+    if (t->tex[0]->width == width && t->tex[0]->height == height) return LUPIN_OK;   // wgpu_utils.rs:343
+    LupinTexture *a = nullptr, *b = nullptr;
+    int rc = lupin_hip_texture_create(t->ctx, width, height, &a);
+    if (rc == LUPIN_OK) rc = lupin_hip_texture_create(t->ctx, width, height, &b);
+    if (rc != LUPIN_OK) { lupin_hip_texture_destroy(a); return rc; }
+    lupin_hip_texture_destroy(t->tex[0]);
+    lupin_hip_texture_destroy(t->tex[1]);
+    t->tex[0] = a; t->tex[1] = b;
+    return LUPIN_OK;
+}
+
+// ---- the hot path ----
+
+int lupin_hip_pathtrace_scene(LupinContext *ctx, const LupinPathtraceResources *res, const LupinScene *scene,
+                              LupinTexture *render_target, uint32_t pathtrace_type, const LupinPathtraceDesc *desc)
+{
+    if (!ctx || !res || !scene || !render_target || !desc) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
+    if (pathtrace_type > LUPIN_PATHTRACE_DIRECT) return fail(LUPIN_ERR_INVALID_ARGUMENT, "unknown pathtrace_type");
+    if (!scene->has_sw_bvh) return fail(LUPIN_ERR_NO_SW_BVH, "no software BVH was built for this scene");   // renderer.rs:774-777
+    const uint32_t W = render_target->width, H = render_target->height;
+    const LupinTexture *prev = desc->accum_params ? desc->accum_params->prev_frame : nullptr;
+    if (prev && prev == render_target) return fail(LUPIN_ERR_SAME_TARGET, "render_target must differ from accum_params.prev_frame");
+    if (prev && (prev->width != W || prev->height != H)) return fail(LUPIN_ERR_INVALID_ARGUMENT, "prev_frame size differs from render_target");
+    HIP_TRY(hipSetDevice(ctx->device));
+
+    FrameParams fp;
+    memset(&fp, 0, sizeof(fp));
+    // get_push_constants (renderer.rs:1426-1493)
+    LupinPushConstants &pc = fp.pc;
+    if (desc->camera_params.is_orthographic) pc.flags |= LUPIN_FLAG_CAMERA_ORTHO;
+    const LupinMat3x4 &ct = desc->camera_transform;   // Mat3x4::to_mat4 (base.rs:695-705)
+    for (int c = 0; c < 4; c++) { pc.camera_transform.m[c][0] = ct.m[c][0]; pc.camera_transform.m[c][1] = ct.m[c][1]; pc.camera_transform.m[c][2] = ct.m[c][2]; pc.camera_transform.m[c][3] = (c == 3) ? 1.0f : 0.0f; }
+    pc.camera_lens = desc->camera_params.lens;
+    pc.camera_film = desc->camera_params.film;
+    pc.camera_aspect = desc->camera_params.aspect;
+    pc.camera_focus = desc->camera_params.focus;
+    pc.camera_aperture = desc->camera_params.aperture;
+    if (scene->envs_empty) pc.flags |= LUPIN_FLAG_ENVS_EMPTY;
+    if (scene->lights_empty) pc.flags |= LUPIN_FLAG_LIGHTS_EMPTY;
+    if (scene->instances_empty) pc.flags |= LUPIN_FLAG_INSTANCES_EMPTY;
+    pc.pathtrace_type = pathtrace_type;
+    pc.accum_counter = desc->accum_params ? desc->accum_params->accum_counter : 0u;
+    pc.max_radiance = desc->advanced.max_radiance;
+    pc.rng_seed = desc->advanced.rng_seed;
+    pc.ray_epsilon = desc->advanced.ray_epsilon;
+
+    // dispatch extent (renderer.rs:807-838)
+    uint32_t groups_x, groups_y;
+    if (desc->tile_params)
+    {
+        uint32_t tile_size = desc->tile_params->tile_size, tile_idx = desc->tile_params->tile_idx;
+        if (tile_size == 0) return fail(LUPIN_ERR_INVALID_ARGUMENT, "tile_size must be > 0");
+        uint32_t ntx = (std::max(1u, W) - 1) / (tile_size * LUPIN_WORKGROUP_SIZE) + 1;
+        uint32_t nty = (std::max(1u, H) - 1) / (tile_size * LUPIN_WORKGROUP_SIZE) + 1;
+        if (tile_idx >= ntx * nty) return fail(LUPIN_ERR_TILE_OUT_OF_RANGE, "tile_idx out of range!");
+        pc.id_offset[0] = (tile_idx % ntx) * tile_size * LUPIN_WORKGROUP_SIZE;
+        pc.id_offset[1] = (tile_idx / ntx) * tile_size * LUPIN_WORKGROUP_SIZE;
+        groups_x = std::min(tile_size, (W - pc.id_offset[0]) / LUPIN_WORKGROUP_SIZE);   // floor: edge remainders are skipped
+        groups_y = std::min(tile_size, (H - pc.id_offset[1]) / LUPIN_WORKGROUP_SIZE);
+    }
+    else
+    {
+        groups_x = (W + LUPIN_WORKGROUP_SIZE - 1) / LUPIN_WORKGROUP_SIZE;
+        groups_y = (H + LUPIN_WORKGROUP_SIZE - 1) / LUPIN_WORKGROUP_SIZE;
+    }
+    fp.width = W; fp.height = H;
+    fp.off_x = pc.id_offset[0]; fp.off_y = pc.id_offset[1];
+    fp.reg_w = std::min(groups_x * LUPIN_WORKGROUP_SIZE, W - fp.off_x);   // texels outside the image are never stored (:287)
+    fp.reg_h = std::min(groups_y * LUPIN_WORKGROUP_SIZE, H - fp.off_y);
+    fp.max_bounces = res->params.max_bounces;
+    fp.spp = res->params.samples_per_pixel;
+    const uint64_t n64 = (uint64_t)fp.reg_w * fp.reg_h;
+    if (n64 == 0) return LUPIN_OK;
+    if (n64 > 0x7FFFFFFFull) return fail(LUPIN_ERR_INVALID_ARGUMENT, "dispatch too large");
+    const uint32_t n = (uint32_t)n64;
+
+    const uint32_t iterations = fp.spp * (fp.max_bounces + 1);
+    int rc = ensure_path_buffers(ctx, n, iterations);
+    if (rc != LUPIN_OK) return rc;
+
+    const uint32_t blocks = (n + LP_BLOCK - 1) / LP_BLOCK;
+    const size_t lds = (size_t)scene->stack_entries * LP_BLOCK * sizeof(uint32_t);
+    if (lds > 160 * 1024) return fail(LUPIN_ERR_INVALID_ARGUMENT, "BVH too deep for the LDS traversal stack");
+
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (ctx->timing) { t0 = get_event(ctx); t1 = get_event(ctx); hipEventRecord(t0, ctx->stream); }
+
+    HIP_TRY(hipMemsetAsync(ctx->pb.counts, 0, (size_t)(iterations + 2) * sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(k_begin, dim3(blocks), dim3(LP_BLOCK), 0, ctx->stream, fp, ctx->pb, n);
+    for (uint32_t it = 0; it < iterations; it++)
+    {
+        switch (pathtrace_type)
+        {
+        case LUPIN_PATHTRACE_STANDARD: launch_iteration<LUPIN_PATHTRACE_STANDARD>(ctx, scene, fp, blocks, lds, it); break;
+        case LUPIN_PATHTRACE_MIS: launch_iteration<LUPIN_PATHTRACE_MIS>(ctx, scene, fp, blocks, lds, it); break;
+        case LUPIN_PATHTRACE_NAIVE: launch_iteration<LUPIN_PATHTRACE_NAIVE>(ctx, scene, fp, blocks, lds, it); break;
+        default: launch_iteration<LUPIN_PATHTRACE_DIRECT>(ctx, scene, fp, blocks, lds, it); break;
+        }
+    }
+    hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(LP_BLOCK), 0, ctx->stream, fp, ctx->pb, n,
+                       prev ? prev->data : (const __half *)nullptr, render_target->data);
+    if (ctx->timing) { hipEventRecord(t1, ctx->stream); ctx->ev_total.push_back({t0, t1}); }
+    HIP_TRY(hipGetLastError());
+    return LUPIN_OK;
+}
+
+// ---- measurement hooks ----
+
+int lupin_hip_stats_reset(LupinContext *ctx, int enable_kernel_timing)
+{
+    if (!ctx) return fail(LUPIN_ERR_INVALID_ARGUMENT, "ctx is null");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->stat_counters, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    // extend/shade pairs share their middle event: recycle each event once
+    for (auto &p : ctx->ev_extend) { ctx->ev_pool.push_back(p.first); ctx->ev_pool.push_back(p.second); }
+    for (auto &p : ctx->ev_shade) { ctx->ev_pool.push_back(p.second); }
+    ctx->ev_extend.clear();
+    ctx->ev_shade.clear();
+    for (auto &p : ctx->ev_total) { ctx->ev_pool.push_back(p.first); ctx->ev_pool.push_back(p.second); }
+    ctx->ev_total.clear();
+    ctx->timing = enable_kernel_timing != 0;
+    ctx->extend_launches = 0;
+    return LUPIN_OK;
+}
+
+int lupin_hip_stats_get(LupinContext *ctx, LupinStats *out)
+{
+    if (!ctx || !out) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    unsigned long long c[2] = {0, 0};
+    HIP_TRY(hipMemcpy(c, ctx->stat_counters, sizeof(c), hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof(*out));
+    out->path_bounces = c[0];
+    out->paths = c[1];
+    out->extend_launches = ctx->extend_launches;
+    auto sum = [](const std::vector<std::pair<hipEvent_t, hipEvent_t>> &v) {
+        double ms = 0.0;
+        for (auto &p : v) { float f = 0.0f; if (hipEventElapsedTime(&f, p.first, p.second) == hipSuccess) ms += f; }
+        return ms;
+    };
+    out->extend_ms = sum(ctx->ev_extend);
+    out->shade_ms = sum(ctx->ev_shade);
+    out->total_ms = sum(ctx->ev_total);
+    return LUPIN_OK;
+}
+
+int lupin_hip_trace_rays(LupinContext *ctx, const LupinScene *scene, uint32_t n, const float *ori_xyz, const float *dir_xyz,
+                         float ray_epsilon, uint32_t *out_hit, float *out_dst, float *out_uv, uint32_t *out_instance, uint32_t *out_tri)
+{
+    if (!ctx || !scene || !ori_xyz || !dir_xyz || !out_hit || !out_dst || !out_uv || !out_instance || !out_tri) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return LUPIN_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    float *d_ori = nullptr, *d_dir = nullptr, *d_dst = nullptr, *d_uv = nullptr;
+    uint32_t *d_hit = nullptr, *d_inst = nullptr, *d_tri = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_ori, (size_t)n * 12));
+    HIP_TRY(hipMalloc((void **)&d_dir, (size_t)n * 12));
+    HIP_TRY(hipMalloc((void **)&d_dst, (size_t)n * 4));
+    HIP_TRY(hipMalloc((void **)&d_uv, (size_t)n * 8));
+    HIP_TRY(hipMalloc((void **)&d_hit, (size_t)n * 4));
+    HIP_TRY(hipMalloc((void **)&d_inst, (size_t)n * 4));
+    HIP_TRY(hipMalloc((void **)&d_tri, (size_t)n * 4));
+    HIP_TRY(hipMemcpyAsync(d_ori, ori_xyz, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_dir, dir_xyz, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+    size_t lds = (size_t)scene->stack_entries * LP_BLOCK * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_trace, dim3((n + LP_BLOCK - 1) / LP_BLOCK), dim3(LP_BLOCK), lds, ctx->stream, scene->dev, n, d_ori, d_dir, ray_epsilon,
+                       d_hit, d_dst, d_uv, d_inst, d_tri);
+    HIP_TRY(hipMemcpyAsync(out_hit, d_hit, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out_dst, d_dst, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out_uv, d_uv, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out_instance, d_inst, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out_tri, d_tri, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    hipFree(d_ori); hipFree(d_dir); hipFree(d_dst); hipFree(d_uv); hipFree(d_hit); hipFree(d_inst); hipFree(d_tri);
+    return LUPIN_OK;
+}
+
+static int pack_common(LupinContext *ctx, const LupinTexture *tex, uint32_t tile_size, uint32_t rank, uint32_t world, void *packed, int unpack)
+{
+    if (!ctx || !tex || !packed || tile_size == 0 || world == 0 || rank >= world) return fail(LUPIN_ERR_INVALID_ARGUMENT, "bad pack arguments");
+    HIP_TRY(hipSetDevice(ctx->device));
+    dim3 block(LP_BLOCK, 1, 1), grid((tex->width + LP_BLOCK - 1) / LP_BLOCK, tex->height, 1);
+    hipLaunchKernelGGL(k_pack_tiles, grid, block, 0, ctx->stream, (const uint2 *)tex->data, (uint2 *)packed, tex->width, tex->height,
+                       tile_size * LUPIN_WORKGROUP_SIZE, rank, world, unpack);
+    HIP_TRY(hipGetLastError());
+    return LUPIN_OK;
+}
+int lupin_hip_pack_tiles(LupinContext *ctx, const LupinTexture *tex, uint32_t tile_size, uint32_t rank, uint32_t world, void *device_dst, uint64_t *out_pixels)
+{
+    int rc = pack_common(ctx, tex, tile_size, rank, world, device_dst, 0);
+    if (rc == LUPIN_OK && out_pixels) *out_pixels = lupin_hip_packed_tile_pixels(tex->width, tex->height, tile_size, rank, world);
+    return rc;
+}
+int lupin_hip_unpack_tiles(LupinContext *ctx, LupinTexture *tex, uint32_t tile_size, uint32_t rank, uint32_t world, const void *device_src)
+{
+    return pack_common(ctx, tex, tile_size, rank, world, const_cast<void *>(device_src), 1);
+}
+
+}  // extern "C"
