@@ -319,6 +319,13 @@ void lupin_hip_destroy_context(LupinContext *ctx);
 /* device.poll(wait_indefinitely) (loader.rs:1692,1825) */
 int lupin_hip_sync(LupinContext *ctx);
 
+/* f32 -> f16 rounding of the Rgba16Float store (pathtracer.wgsl:288).  WGSL leaves it to the device;
+ * the reference's golden renders are reproduced by round-toward-zero, which is the
+ * default.  mode: 0 = toward zero, 1 = nearest even. */
+#define LUPIN_STORE_ROUND_TOWARD_ZERO 0
+#define LUPIN_STORE_ROUND_NEAREST_EVEN 1
+int lupin_hip_set_f16_store_rounding(LupinContext *ctx, int mode);
+
 /* lp::build_pathtrace_resources (renderer.rs:470-642): bakes max_bounces / samples_per_pixel */
 int lupin_hip_build_pathtrace_resources(LupinContext *ctx, const LupinBakedPathtraceParams *params,
                                         LupinPathtraceResources **out_res);
@@ -356,6 +363,16 @@ uint32_t lupin_hip_get_num_tiles(uint32_t tile_size, uint32_t width, uint32_t he
 int lupin_hip_pathtrace_scene(LupinContext *ctx, const LupinPathtraceResources *res,
                               const LupinScene *scene, LupinTexture *render_target,
                               uint32_t pathtrace_type, const LupinPathtraceDesc *desc);
+
+/* Tile-sharded variant for multi-GPU rendering (extension; the reference renders tiles one
+ * sub-dispatch at a time on one device, renderer.rs:807-829): renders, in ONE wavefront launch,
+ * every tile t of the frame with t % world == rank (tiles of tile_size*4 pixels, numbered
+ * row-major as renderer.rs:816-817).  Edge tiles cover all in-bounds pixels, so the union over
+ * ranks equals the full-screen dispatch bit for bit.  desc->tile_params is ignored. */
+int lupin_hip_pathtrace_scene_tiles(LupinContext *ctx, const LupinPathtraceResources *res,
+                                    const LupinScene *scene, LupinTexture *render_target,
+                                    uint32_t pathtrace_type, const LupinPathtraceDesc *desc,
+                                    uint32_t tile_size, uint32_t rank, uint32_t world);
 
 /* ---- measurement hooks (no reference counterpart; the reference exposes none) ---- */
 

@@ -137,6 +137,7 @@ SYMBOLS = [
     ("lupin_hip_create_context", C.c_int, [C.c_int, _PP]),
     ("lupin_hip_destroy_context", None, [_P]),
     ("lupin_hip_sync", C.c_int, [_P]),
+    ("lupin_hip_set_f16_store_rounding", C.c_int, [_P, C.c_int]),
     ("lupin_hip_build_pathtrace_resources", C.c_int, [_P, C.POINTER(BakedPathtraceParamsC), _PP]),
     ("lupin_hip_destroy_pathtrace_resources", None, [_P]),
     ("lupin_hip_scene_create", C.c_int, [_P, C.POINTER(SceneDesc), _PP]),
@@ -157,6 +158,7 @@ SYMBOLS = [
     ("lupin_hip_dbuf_resize", C.c_int, [_P, _U32, _U32]),
     ("lupin_hip_get_num_tiles", _U32, [_U32, _U32, _U32]),
     ("lupin_hip_pathtrace_scene", C.c_int, [_P, _P, _P, _P, _U32, C.POINTER(PathtraceDescC)]),
+    ("lupin_hip_pathtrace_scene_tiles", C.c_int, [_P, _P, _P, _P, _U32, C.POINTER(PathtraceDescC), _U32, _U32, _U32]),
     ("lupin_hip_stats_reset", C.c_int, [_P, C.c_int]),
     ("lupin_hip_stats_get", C.c_int, [_P, C.POINTER(StatsC)]),
     ("lupin_hip_trace_rays", C.c_int, [_P, _P, _U32, _P, _P, C.c_float, _P, _P, _P, _P, _P]),

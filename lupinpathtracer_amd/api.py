@@ -119,6 +119,10 @@ class Context:
     def sync(self):
         check(lib().lupin_hip_sync(self.handle))
 
+    def set_f16_store_rounding(self, mode):
+        """0 = toward zero (what the reference's goldens show; default), 1 = nearest even."""
+        check(lib().lupin_hip_set_f16_store_rounding(self.handle, int(mode)))
+
     def stats_reset(self, kernel_timing=False):
         check(lib().lupin_hip_stats_reset(self.handle, 1 if kernel_timing else 0))
 
@@ -606,6 +610,31 @@ def pathtrace_scene(ctx, resources, scene, render_target, pathtrace_type, desc):
     c = _desc_to_c(desc, keep)
     check(lib().lupin_hip_pathtrace_scene(ctx.handle, resources.handle, scene.handle, render_target.handle,
                                           int(pathtrace_type), C.byref(c)))
+
+
+def pathtrace_scene_tiles(ctx, resources, scene, render_target, pathtrace_type, desc, tile_size, rank, world):
+    """Multi-GPU extension: all tiles t with t % world == rank of one accumulation frame, in one launch."""
+    assert render_target.format() == "Rgba16Float"
+    if scene.handle is None:
+        raise LupinError(_abi_code("LUPIN_ERR_NO_DEVICE"), "scene was built without a device context; there is no CPU fallback")
+    keep = []
+    c = _desc_to_c(desc, keep)
+    check(lib().lupin_hip_pathtrace_scene_tiles(ctx.handle, resources.handle, scene.handle, render_target.handle,
+                                                int(pathtrace_type), C.byref(c), tile_size, rank, world))
+
+
+def pack_tiles(ctx, texture, tile_size, rank, world, device_dst_ptr):
+    n = C.c_uint64()
+    check(lib().lupin_hip_pack_tiles(ctx.handle, texture.handle, tile_size, rank, world, C.c_void_p(device_dst_ptr), C.byref(n)))
+    return int(n.value)
+
+
+def unpack_tiles(ctx, texture, tile_size, rank, world, device_src_ptr):
+    check(lib().lupin_hip_unpack_tiles(ctx.handle, texture.handle, tile_size, rank, world, C.c_void_p(device_src_ptr)))
+
+
+def packed_tile_pixels(width, height, tile_size, rank, world):
+    return int(lib().lupin_hip_packed_tile_pixels(width, height, tile_size, rank, world))
 
 
 def _abi_code(name):

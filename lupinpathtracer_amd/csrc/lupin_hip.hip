@@ -65,6 +65,10 @@ struct FrameParams
     uint32_t off_x, off_y;       // dispatch origin (id_offset)
     uint32_t reg_w, reg_h;       // in-bounds pixels of the dispatch
     uint32_t max_bounces, spp;
+    // tile-set dispatch (multi-GPU sharding): slot -> pixel goes through the list of owned tiles
+    uint32_t store_rne;          // f32 -> f16 store rounding: 0 = toward zero (reference goldens), 1 = nearest even
+    uint32_t tile_px;            // 0 = rectangular dispatch
+    uint32_t tiles_x, rank, world;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -120,8 +124,32 @@ __device__ void camera_ray(const FrameParams &fp, uint32_t gx, uint32_t gy, uint
 
 __device__ __forceinline__ void slot_to_pixel(const FrameParams &fp, uint32_t slot, uint32_t &gx, uint32_t &gy)
 {
+    if (fp.tile_px)
+    {
+        const uint32_t per_tile = fp.tile_px * fp.tile_px;
+        const uint32_t t = fp.rank + (slot / per_tile) * fp.world;
+        const uint32_t r = slot % per_tile;
+        gx = (t % fp.tiles_x) * fp.tile_px + r % fp.tile_px;
+        gy = (t / fp.tiles_x) * fp.tile_px + r / fp.tile_px;
+        return;
+    }
     gx = fp.off_x + slot % fp.reg_w;
     gy = fp.off_y + slot / fp.reg_w;
+}
+
+// append the lanes with `alive` to a queue: one atomic per wave
+__device__ __forceinline__ void queue_append(bool alive, uint32_t slot, uint32_t *queue, uint32_t *counter)
+{
+    const unsigned long long mask = __ballot(alive);
+    if (mask)
+    {
+        const int lane = threadIdx.x & 63;
+        const int leader = __ffsll((long long)mask) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+        base = __shfl(base, leader);
+        if (alive) queue[base + __popcll(mask & ((1ull << lane) - 1ull))] = slot;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -131,10 +159,15 @@ __device__ __forceinline__ void slot_to_pixel(const FrameParams &fp, uint32_t sl
 __global__ void __launch_bounds__(LP_BLOCK) k_begin(FrameParams fp, PathBuffers pb, uint32_t n)
 {
     uint32_t slot = blockIdx.x * LP_BLOCK + threadIdx.x;
-    if (slot == 0) pb.counts[0] = n;
-    if (slot >= n) return;
-    uint32_t gx, gy;
-    slot_to_pixel(fp, slot, gx, gy);
+    uint32_t gx = 0, gy = 0;
+    bool live = slot < n;
+    if (live)
+    {
+        slot_to_pixel(fp, slot, gx, gy);
+        live = gx < fp.width && gy < fp.height;   // edge tiles: texels outside the image are never stored (:287)
+    }
+    queue_append(live, slot, pb.queue[0], &pb.counts[0]);
+    if (!live) return;
     uint32_t rng = rng_seed_for(gy * fp.width + gx, fp.pc.accum_counter);
     f3 o, d;
     camera_ray(fp, gx, gy, rng, o, d);
@@ -145,7 +178,6 @@ __global__ void __launch_bounds__(LP_BLOCK) k_begin(FrameParams fp, PathBuffers 
     pb.color[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     pb.next_hit[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(HIT_MISS));   // `var next_intersection = HitInfo()` (:746)
     pb.next_tri[slot] = 0u;
-    pb.queue[0][slot] = slot;
 }
 
 // ray_skip_alpha_stochastically (bvh_custom.wgsl:154-180).  The material is consulted only for
@@ -509,17 +541,7 @@ __global__ void __launch_bounds__(LP_BLOCK) k_shade(SceneDev sc, FrameParams fp,
     }
     if (i == 0 && iter == 0 && path_counter) atomicAdd(path_counter, (unsigned long long)count * fp.spp);
 
-    // append survivors to the next queue: one atomic per wave
-    const unsigned long long mask = __ballot(alive);
-    if (mask)
-    {
-        const int lane = threadIdx.x & 63;
-        const int leader = __ffsll((long long)mask) - 1;
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(&pb.counts[iter + 1], (uint32_t)__popcll(mask));
-        base = __shfl(base, leader);
-        if (alive) pb.queue[(iter + 1) & 1][base + __popcll(mask & ((1ull << lane) - 1ull))] = slot;
-    }
+    queue_append(alive, slot, pb.queue[(iter + 1) & 1], &pb.counts[iter + 1]);
 }
 
 // pathtrace_main tail (pathtracer.wgsl:275-289)
@@ -530,6 +552,7 @@ __global__ void __launch_bounds__(LP_BLOCK) k_resolve(FrameParams fp, PathBuffer
     if (slot >= n) return;
     uint32_t gx, gy;
     slot_to_pixel(fp, slot, gx, gy);
+    if (gx >= fp.width || gy >= fp.height) return;
     float4 c4 = pb.color[slot];
     float spp = (float)fp.spp;
     f3 c = mk3(maxf(c4.x / spp, 0.0f), maxf(c4.y / spp, 0.0f), maxf(c4.z / spp, 0.0f));
@@ -540,9 +563,18 @@ __global__ void __launch_bounds__(LP_BLOCK) k_resolve(FrameParams fp, PathBuffer
         f3 pc = mk3(__half2float(prev[px + 0]), __half2float(prev[px + 1]), __half2float(prev[px + 2]));
         c = mk3(maxf(pc.x * (1.0f - w) + c.x * w, 0.0f), maxf(pc.y * (1.0f - w) + c.y * w, 0.0f), maxf(pc.z * (1.0f - w) + c.z * w, 0.0f));
     }
-    out[px + 0] = __float2half_rn(c.x);
-    out[px + 1] = __float2half_rn(c.y);
-    out[px + 2] = __float2half_rn(c.z);
+    if (fp.store_rne)
+    {
+        out[px + 0] = __float2half_rn(c.x);
+        out[px + 1] = __float2half_rn(c.y);
+        out[px + 2] = __float2half_rn(c.z);
+    }
+    else
+    {
+        out[px + 0] = __float2half_rz(c.x);
+        out[px + 1] = __float2half_rz(c.y);
+        out[px + 2] = __float2half_rz(c.z);
+    }
     out[px + 3] = __float2half_rn(1.0f);
 }
 
@@ -614,6 +646,7 @@ struct LupinContext
     uint32_t counts_capacity = 0;
     unsigned long long *stat_counters = nullptr;   // [0] path bounces, [1] paths
     bool timing = false;
+    int store_rounding = 0;        // LUPIN_STORE_ROUND_TOWARD_ZERO
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_extend, ev_shade, ev_total;
     std::vector<hipEvent_t> ev_pool;
     uint64_t extend_launches = 0;
@@ -788,6 +821,13 @@ int lupin_hip_sync(LupinContext *ctx)
     if (!ctx) return fail(LUPIN_ERR_INVALID_ARGUMENT, "ctx is null");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return LUPIN_OK;
+}
+
+int lupin_hip_set_f16_store_rounding(LupinContext *ctx, int mode)
+{
+    if (!ctx || (mode != 0 && mode != 1)) return fail(LUPIN_ERR_INVALID_ARGUMENT, "mode must be 0 (toward zero) or 1 (nearest even)");
+    ctx->store_rounding = mode;
     return LUPIN_OK;
 }
 
@@ -1202,8 +1242,9 @@ int lupin_hip_dbuf_resize(LupinDoubleBufferedTexture *t, uint32_t width, uint32_
 
 // ---- the hot path ----
 
-int lupin_hip_pathtrace_scene(LupinContext *ctx, const LupinPathtraceResources *res, const LupinScene *scene,
-                              LupinTexture *render_target, uint32_t pathtrace_type, const LupinPathtraceDesc *desc)
+static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res, const LupinScene *scene,
+                          LupinTexture *render_target, uint32_t pathtrace_type, const LupinPathtraceDesc *desc,
+                          bool tile_set, uint32_t set_tile_size, uint32_t rank, uint32_t world)
 {
     if (!ctx || !res || !scene || !render_target || !desc) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
     if (pathtrace_type > LUPIN_PATHTRACE_DIRECT) return fail(LUPIN_ERR_INVALID_ARGUMENT, "unknown pathtrace_type");
@@ -1235,32 +1276,47 @@ int lupin_hip_pathtrace_scene(LupinContext *ctx, const LupinPathtraceResources *
     pc.rng_seed = desc->advanced.rng_seed;
     pc.ray_epsilon = desc->advanced.ray_epsilon;
 
-    // dispatch extent (renderer.rs:807-838)
-    uint32_t groups_x, groups_y;
-    if (desc->tile_params)
+    fp.width = W; fp.height = H;
+    fp.store_rne = (ctx->store_rounding == 1) ? 1u : 0u;
+    fp.max_bounces = res->params.max_bounces;
+    fp.spp = res->params.samples_per_pixel;
+    uint64_t n64;
+    if (tile_set)
     {
-        uint32_t tile_size = desc->tile_params->tile_size, tile_idx = desc->tile_params->tile_idx;
-        if (tile_size == 0) return fail(LUPIN_ERR_INVALID_ARGUMENT, "tile_size must be > 0");
-        uint32_t ntx = (std::max(1u, W) - 1) / (tile_size * LUPIN_WORKGROUP_SIZE) + 1;
-        uint32_t nty = (std::max(1u, H) - 1) / (tile_size * LUPIN_WORKGROUP_SIZE) + 1;
-        if (tile_idx >= ntx * nty) return fail(LUPIN_ERR_TILE_OUT_OF_RANGE, "tile_idx out of range!");
-        pc.id_offset[0] = (tile_idx % ntx) * tile_size * LUPIN_WORKGROUP_SIZE;
-        pc.id_offset[1] = (tile_idx / ntx) * tile_size * LUPIN_WORKGROUP_SIZE;
-        groups_x = std::min(tile_size, (W - pc.id_offset[0]) / LUPIN_WORKGROUP_SIZE);   // floor: edge remainders are skipped
-        groups_y = std::min(tile_size, (H - pc.id_offset[1]) / LUPIN_WORKGROUP_SIZE);
+        if (set_tile_size == 0 || world == 0 || rank >= world) return fail(LUPIN_ERR_INVALID_ARGUMENT, "bad tile-set arguments");
+        const uint32_t tpx = set_tile_size * LUPIN_WORKGROUP_SIZE;
+        const uint32_t ntx = (std::max(1u, W) - 1) / tpx + 1, nty = (std::max(1u, H) - 1) / tpx + 1;
+        const uint32_t total = ntx * nty;
+        const uint32_t owned = (total > rank) ? (total - rank + world - 1) / world : 0;
+        fp.tile_px = tpx; fp.tiles_x = ntx; fp.rank = rank; fp.world = world;
+        n64 = (uint64_t)owned * tpx * tpx;
     }
     else
     {
-        groups_x = (W + LUPIN_WORKGROUP_SIZE - 1) / LUPIN_WORKGROUP_SIZE;
-        groups_y = (H + LUPIN_WORKGROUP_SIZE - 1) / LUPIN_WORKGROUP_SIZE;
+        // dispatch extent (renderer.rs:807-838)
+        uint32_t groups_x, groups_y;
+        if (desc->tile_params)
+        {
+            uint32_t tile_size = desc->tile_params->tile_size, tile_idx = desc->tile_params->tile_idx;
+            if (tile_size == 0) return fail(LUPIN_ERR_INVALID_ARGUMENT, "tile_size must be > 0");
+            uint32_t ntx = (std::max(1u, W) - 1) / (tile_size * LUPIN_WORKGROUP_SIZE) + 1;
+            uint32_t nty = (std::max(1u, H) - 1) / (tile_size * LUPIN_WORKGROUP_SIZE) + 1;
+            if (tile_idx >= ntx * nty) return fail(LUPIN_ERR_TILE_OUT_OF_RANGE, "tile_idx out of range!");
+            pc.id_offset[0] = (tile_idx % ntx) * tile_size * LUPIN_WORKGROUP_SIZE;
+            pc.id_offset[1] = (tile_idx / ntx) * tile_size * LUPIN_WORKGROUP_SIZE;
+            groups_x = std::min(tile_size, (W - pc.id_offset[0]) / LUPIN_WORKGROUP_SIZE);   // floor: edge remainders are skipped
+            groups_y = std::min(tile_size, (H - pc.id_offset[1]) / LUPIN_WORKGROUP_SIZE);
+        }
+        else
+        {
+            groups_x = (W + LUPIN_WORKGROUP_SIZE - 1) / LUPIN_WORKGROUP_SIZE;
+            groups_y = (H + LUPIN_WORKGROUP_SIZE - 1) / LUPIN_WORKGROUP_SIZE;
+        }
+        fp.off_x = pc.id_offset[0]; fp.off_y = pc.id_offset[1];
+        fp.reg_w = std::min(groups_x * LUPIN_WORKGROUP_SIZE, W - fp.off_x);   // texels outside the image are never stored (:287)
+        fp.reg_h = std::min(groups_y * LUPIN_WORKGROUP_SIZE, H - fp.off_y);
+        n64 = (uint64_t)fp.reg_w * fp.reg_h;
     }
-    fp.width = W; fp.height = H;
-    fp.off_x = pc.id_offset[0]; fp.off_y = pc.id_offset[1];
-    fp.reg_w = std::min(groups_x * LUPIN_WORKGROUP_SIZE, W - fp.off_x);   // texels outside the image are never stored (:287)
-    fp.reg_h = std::min(groups_y * LUPIN_WORKGROUP_SIZE, H - fp.off_y);
-    fp.max_bounces = res->params.max_bounces;
-    fp.spp = res->params.samples_per_pixel;
-    const uint64_t n64 = (uint64_t)fp.reg_w * fp.reg_h;
     if (n64 == 0) return LUPIN_OK;
     if (n64 > 0x7FFFFFFFull) return fail(LUPIN_ERR_INVALID_ARGUMENT, "dispatch too large");
     const uint32_t n = (uint32_t)n64;
@@ -1293,6 +1349,19 @@ int lupin_hip_pathtrace_scene(LupinContext *ctx, const LupinPathtraceResources *
     if (ctx->timing) { hipEventRecord(t1, ctx->stream); ctx->ev_total.push_back({t0, t1}); }
     HIP_TRY(hipGetLastError());
     return LUPIN_OK;
+}
+
+int lupin_hip_pathtrace_scene(LupinContext *ctx, const LupinPathtraceResources *res, const LupinScene *scene,
+                              LupinTexture *render_target, uint32_t pathtrace_type, const LupinPathtraceDesc *desc)
+{
+    return pathtrace_impl(ctx, res, scene, render_target, pathtrace_type, desc, false, 0, 0, 1);
+}
+
+int lupin_hip_pathtrace_scene_tiles(LupinContext *ctx, const LupinPathtraceResources *res, const LupinScene *scene,
+                                    LupinTexture *render_target, uint32_t pathtrace_type, const LupinPathtraceDesc *desc,
+                                    uint32_t tile_size, uint32_t rank, uint32_t world)
+{
+    return pathtrace_impl(ctx, res, scene, render_target, pathtrace_type, desc, true, tile_size, rank, world);
 }
 
 // ---- measurement hooks ----

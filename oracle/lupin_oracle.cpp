@@ -19,7 +19,11 @@
 //   * pow(x, 2.0) is x*x (what every Vulkan compiler folds it to; pow of a negative base is
 //     otherwise undefined in WGSL) -- pathtracer.wgsl:2067,2190;
 //   * textureSampleLevel = software bilinear, Repeat addressing, level 0, texel centres at +0.5;
-//   * textureStore to rgba16float rounds to nearest even.
+//   * textureStore to rgba16float: WGSL/Vulkan leave the f32->f16 rounding to the device (RTE or
+//     RTZ).  The reference's golden renders pin it: replaying lupin_tests' 101-frame protocol with
+//     round-toward-zero stores reproduces their image means to 1e-4, round-to-nearest-even comes out
+//     1.8 % brighter (truncation error accumulates in the running average).  Default = RTZ;
+//     RTE selectable (store_rounding = 1).
 //
 // Build: see oracle/Makefile (g++ -O2 -ffp-contract=off -fopenmp).
 
@@ -163,6 +167,14 @@ inline uint16_t float_to_half_rne(float f)
     return (uint16_t)(sign | h);
 }
 
+inline uint16_t float_to_half_rtz(float f)
+{
+    uint16_t h = float_to_half_rne(f);
+    if ((h & 0x7FFFu) > 0x7C00u) return h;   // NaN
+    if (fabsf(half_to_float(h)) > fabsf(f)) h = (uint16_t)(h - 1);   // rounded away from zero (incl. to inf): step back
+    return h;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Per-invocation state (WGSL `var<private>`), scene bindings and counters
 // ---------------------------------------------------------------------------------------------
@@ -194,12 +206,18 @@ struct MaterialPoint  // :1247-1260
     float tr_depth = 0;
 };
 
+// Work accounting.  Traversal work is split by who asked for it, because the HIP
+// build runs the three kinds in different kernels:
+//   ctx 0: the integrator's closest-hit query (ray_skip_alpha_stochastically)   -> extend stage
+//   ctx 1: light-pdf marching (compute_instance_lights_pdf)                      -> shade stage
+//   ctx 2: shadow / MIS closest-hit queries issued from inside the loop body    -> shade stage
 struct Counters
 {
     uint64_t path_bounces = 0, paths = 0;
-    uint64_t tlas_aabb = 0, instances_entered = 0, blas_aabb = 0, tri_tests = 0;
+    uint64_t tlas_aabb[3] = {0, 0, 0}, instances_entered[3] = {0, 0, 0}, blas_aabb[3] = {0, 0, 0}, tri_tests[3] = {0, 0, 0};
     uint64_t material_points = 0, tex_ldr = 0, tex_hdr = 0, light_mesh = 0, light_env = 0;
-    uint64_t closest_hit_queries = 0, light_pdf_queries = 0;
+    uint64_t closest_hit_queries = 0, light_pdf_queries = 0, surface_hits = 0;
+    uint64_t normal_fetches = 0, uv_fetches = 0, color_fetches = 0;   // 3-vertex attribute gathers
 };
 
 const int MAX_VOLUMES = 10;                 // :582
@@ -214,6 +232,7 @@ struct Inv
     uint32_t MAX_BOUNCES, SAMPLES_PER_PIXEL;
     uint32_t RNG_STATE = 0;
     Counters n;
+    int wctx = 2;   // which traversal context is charged (see Counters)
 
     // ---- RNG (pathtracer.wgsl:1561-1629, :1675-1679) ----
     static uint32_t hash_u32(uint32_t seed)  // :1569-1580
@@ -348,7 +367,7 @@ struct Inv
                     vec3f v2 = vert_pos(mesh_idx, index(mesh_idx, i * 3 + 2));
                     vec4f hit = ray_tri_dst(ray, v0, v1, v2);
                     if (hit.x < min_hit.x) { min_hit = hit; tri_idx = i; }
-                    n.tri_tests++;
+                    n.tri_tests[wctx]++;
                 }
             }
             else
@@ -359,7 +378,7 @@ struct Inv
                 const LupinBvhNode &r = nodes[right_child];
                 float left_dst = ray_aabb_dst(ray, v3(l.aabb_min[0], l.aabb_min[1], l.aabb_min[2]), v3(l.aabb_max[0], l.aabb_max[1], l.aabb_max[2]));
                 float right_dst = ray_aabb_dst(ray, v3(r.aabb_min[0], r.aabb_min[1], r.aabb_min[2]), v3(r.aabb_max[0], r.aabb_max[1], r.aabb_max[2]));
-                n.blas_aabb += 2;
+                n.blas_aabb[wctx] += 2;
 
                 bool visit_left_first = left_dst <= right_dst;
                 bool push_left = left_dst < min_hit.x;
@@ -400,7 +419,7 @@ struct Inv
             if (node.left == 0u)  // leaf
             {
                 const LupinInstance &instance = s->instances[node.instance_idx];
-                n.instances_entered++;
+                n.instances_entered[wctx]++;
                 Ray ray_trans = ray;
                 vec4f c0 = tit(instance, 0), c1 = tit(instance, 1), c2 = tit(instance, 2);
                 // vec4f(ori, 1) * mat3x4 : dot with each column (:32)
@@ -427,7 +446,7 @@ struct Inv
                 const LupinTlasNode &r = s->tlas_nodes[node.right];
                 float left_dst = ray_aabb_dst(ray, v3(l.aabb_min[0], l.aabb_min[1], l.aabb_min[2]), v3(l.aabb_max[0], l.aabb_max[1], l.aabb_max[2]));
                 float right_dst = ray_aabb_dst(ray, v3(r.aabb_min[0], r.aabb_min[1], r.aabb_min[2]), v3(r.aabb_max[0], r.aabb_max[1], r.aabb_max[2]));
-                n.tlas_aabb += 2;
+                n.tlas_aabb[wctx] += 2;
 
                 bool visit_left_first = left_dst <= right_dst;
                 bool push_left = left_dst < min_hit.x;
@@ -537,7 +556,11 @@ struct Inv
             {
                 Ray ray = {next_pos, incoming, 1.0f / incoming};
                 n.light_pdf_queries++;
+                const int saved_ctx = wctx;
+                wctx = 1;
+                n.instances_entered[1]++;
                 RayMeshIntersectionResult hit_info = _ray_instance_intersection(ray, F32_MAX, instance_idx);
+                wctx = saved_ctx;
                 float hit_dst = hit_info.hit.x;
                 if (hit_dst == F32_MAX) { break; }
                 vec3f light_normal = compute_tri_geom_normal(instance_idx, hit_info.tri_idx);
@@ -597,6 +620,7 @@ struct Inv
         uint32_t mesh_idx = s->instances[instance_idx].mesh_idx;
         const LupinMeshInfo &mesh_info = s->mesh_infos[mesh_idx];
         if (mesh_info.colors_buf_idx == SENTINEL_IDX) { return {1.0f, 1.0f, 1.0f, 1.0f}; }
+        const_cast<Inv *>(this)->n.color_fetches++;
         vec4f c0 = vert_color(mesh_info.colors_buf_idx, index(mesh_idx, tri_idx * 3 + 0));
         vec4f c1 = vert_color(mesh_info.colors_buf_idx, index(mesh_idx, tri_idx * 3 + 1));
         vec4f c2 = vert_color(mesh_info.colors_buf_idx, index(mesh_idx, tri_idx * 3 + 2));
@@ -625,6 +649,7 @@ struct Inv
         vec3f scattering_sample = v3(1.0f);
         if (mesh_info.texcoords_buf_idx != SENTINEL_IDX)
         {
+            n.uv_fetches++;
             vec2f uv0 = vert_uv(mesh_info.texcoords_buf_idx, index(mesh_idx, tri_idx * 3 + 0));
             vec2f uv1 = vert_uv(mesh_info.texcoords_buf_idx, index(mesh_idx, tri_idx * 3 + 1));
             vec2f uv2 = vert_uv(mesh_info.texcoords_buf_idx, index(mesh_idx, tri_idx * 3 + 2));
@@ -692,7 +717,9 @@ struct Inv
         float dst = 0.0f;
         for (uint32_t opacity_bounce = 0u; opacity_bounce < MAX_OPACITY_BOUNCES; opacity_bounce++)
         {
+            wctx = 0;
             hit = ray_scene_intersection(ray);
+            wctx = 2;
             if (!hit.hit) { break; }
             dst += hit.dst;
             MaterialPoint mat_point = get_material_point(hit);
@@ -740,6 +767,7 @@ struct Inv
         }
         else
         {
+            const_cast<Inv *>(this)->n.normal_fetches++;
             vec3f n0 = vert_normal(mesh_info.normals_buf_idx, index(mesh_idx, tri_idx * 3 + 0));
             vec3f n1 = vert_normal(mesh_info.normals_buf_idx, index(mesh_idx, tri_idx * 3 + 1));
             vec3f n2 = vert_normal(mesh_info.normals_buf_idx, index(mesh_idx, tri_idx * 3 + 2));
@@ -758,6 +786,7 @@ struct Inv
     // :1344-1384
     vec3f compute_shading_normal(const HitInfo &hit)
     {
+        n.surface_hits++;
         const LupinInstance &instance = s->instances[hit.instance_idx];
         uint32_t mesh_idx = instance.mesh_idx;
         const LupinMeshInfo &mesh_info = s->mesh_infos[mesh_idx];
@@ -2066,8 +2095,13 @@ struct Inv
 void accumulate(Counters &a, const Counters &b)
 {
     a.path_bounces += b.path_bounces; a.paths += b.paths;
-    a.tlas_aabb += b.tlas_aabb; a.instances_entered += b.instances_entered;
-    a.blas_aabb += b.blas_aabb; a.tri_tests += b.tri_tests;
+    for (int k = 0; k < 3; k++)
+    {
+        a.tlas_aabb[k] += b.tlas_aabb[k]; a.instances_entered[k] += b.instances_entered[k];
+        a.blas_aabb[k] += b.blas_aabb[k]; a.tri_tests[k] += b.tri_tests[k];
+    }
+    a.surface_hits += b.surface_hits;
+    a.normal_fetches += b.normal_fetches; a.uv_fetches += b.uv_fetches; a.color_fetches += b.color_fetches;
     a.material_points += b.material_points; a.tex_ldr += b.tex_ldr; a.tex_hdr += b.tex_hdr;
     a.light_mesh += b.light_mesh; a.light_env += b.light_env;
     a.closest_hit_queries += b.closest_hit_queries; a.light_pdf_queries += b.light_pdf_queries;
@@ -2080,21 +2114,25 @@ extern "C" {
 // Counter record returned to the harness (SURVEY 8d work accounting).
 struct OracleCounters
 {
-    uint64_t path_bounces, paths, tlas_aabb, instances_entered, blas_aabb, tri_tests;
-    uint64_t material_points, tex_ldr, tex_hdr, light_mesh, light_env, closest_hit_queries, light_pdf_queries;
+    uint64_t path_bounces, paths;
+    uint64_t tlas_aabb[3], instances_entered[3], blas_aabb[3], tri_tests[3];   // [extend, light-pdf, shadow]
+    uint64_t material_points, tex_ldr, tex_hdr, light_mesh, light_env, closest_hit_queries, light_pdf_queries, surface_hits;
+    uint64_t normal_fetches, uv_fetches, color_fetches;
 };
 
 // One dispatch of pathtrace_main (pathtracer.wgsl:220-292) over `groups_x` x `groups_y`
 // 4x4-pixel workgroups starting at constants.id_offset, exactly as renderer.rs:807-838 issues it.
 // prev_frame / out_rgba16f: W*H*4 half floats (row 0 = top); prev_frame may be NULL when
 // accum_counter == 0.  out_rgb_f32 (optional, W*H*3) receives the unquantised colour.
+// store_rounding: 0 = toward zero (what the reference's goldens show), 1 = nearest even.
 // Texels outside the dispatch are left untouched.  Returns 0 on success.
 int oracle_pathtrace(const LupinSceneDesc *scene, const LupinPushConstants *constants,
                      uint32_t max_bounces, uint32_t samples_per_pixel,
                      uint32_t width, uint32_t height, uint32_t groups_x, uint32_t groups_y,
                      const uint16_t *prev_frame, uint16_t *out_rgba16f, float *out_rgb_f32,
-                     OracleCounters *counters, int num_threads)
+                     OracleCounters *counters, int num_threads, int store_rounding)
 {
+    auto to_half = [store_rounding](float f) { return store_rounding == 1 ? float_to_half_rne(f) : float_to_half_rtz(f); };
     if (!scene || !constants || !out_rgba16f) return -1;
     if (constants->accum_counter != 0 && !prev_frame) return -1;
     Counters total;
@@ -2119,9 +2157,9 @@ int oracle_pathtrace(const LupinSceneDesc *scene, const LupinPushConstants *cons
                 float rgb[3];
                 inv.pathtrace_main(gx, gy, width, height, prev_frame, rgb);
                 size_t o = (size_t)gy * width + gx;
-                out_rgba16f[o * 4 + 0] = float_to_half_rne(rgb[0]);
-                out_rgba16f[o * 4 + 1] = float_to_half_rne(rgb[1]);
-                out_rgba16f[o * 4 + 2] = float_to_half_rne(rgb[2]);
+                out_rgba16f[o * 4 + 0] = to_half(rgb[0]);
+                out_rgba16f[o * 4 + 1] = to_half(rgb[1]);
+                out_rgba16f[o * 4 + 2] = to_half(rgb[2]);
                 out_rgba16f[o * 4 + 3] = 0x3C00;  // 1.0
                 if (out_rgb_f32) { out_rgb_f32[o * 3 + 0] = rgb[0]; out_rgb_f32[o * 3 + 1] = rgb[1]; out_rgb_f32[o * 3 + 2] = rgb[2]; }
                 accumulate(local, inv.n);
@@ -2133,8 +2171,13 @@ int oracle_pathtrace(const LupinSceneDesc *scene, const LupinPushConstants *cons
     if (counters)
     {
         counters->path_bounces = total.path_bounces; counters->paths = total.paths;
-        counters->tlas_aabb = total.tlas_aabb; counters->instances_entered = total.instances_entered;
-        counters->blas_aabb = total.blas_aabb; counters->tri_tests = total.tri_tests;
+        for (int k = 0; k < 3; k++)
+        {
+            counters->tlas_aabb[k] = total.tlas_aabb[k]; counters->instances_entered[k] = total.instances_entered[k];
+            counters->blas_aabb[k] = total.blas_aabb[k]; counters->tri_tests[k] = total.tri_tests[k];
+        }
+        counters->surface_hits = total.surface_hits;
+        counters->normal_fetches = total.normal_fetches; counters->uv_fetches = total.uv_fetches; counters->color_fetches = total.color_fetches;
         counters->material_points = total.material_points; counters->tex_ldr = total.tex_ldr; counters->tex_hdr = total.tex_hdr;
         counters->light_mesh = total.light_mesh; counters->light_env = total.light_env;
         counters->closest_hit_queries = total.closest_hit_queries; counters->light_pdf_queries = total.light_pdf_queries;
@@ -2203,6 +2246,7 @@ void oracle_bsdf_probe(uint32_t mat_type, const float color[3], float roughness,
 }
 
 uint16_t oracle_float_to_half(float f) { return float_to_half_rne(f); }
+uint16_t oracle_float_to_half_rtz(float f) { return float_to_half_rtz(f); }
 float oracle_half_to_float(uint16_t h) { return half_to_float(h); }
 int oracle_num_threads(void)
 {

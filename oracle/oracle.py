@@ -16,9 +16,11 @@ LIB_PATH = os.path.join(_HERE, "liblupin_oracle.so")
 
 
 class OracleCounters(C.Structure):
-    _fields_ = [(k, C.c_uint64) for k in ("path_bounces", "paths", "tlas_aabb", "instances_entered", "blas_aabb", "tri_tests",
-                                           "material_points", "tex_ldr", "tex_hdr", "light_mesh", "light_env",
-                                           "closest_hit_queries", "light_pdf_queries")]
+    _fields_ = ([("path_bounces", C.c_uint64), ("paths", C.c_uint64)] +
+                [(k, C.c_uint64 * 3) for k in ("tlas_aabb", "instances_entered", "blas_aabb", "tri_tests")] +
+                [(k, C.c_uint64) for k in ("material_points", "tex_ldr", "tex_hdr", "light_mesh", "light_env",
+                                           "closest_hit_queries", "light_pdf_queries", "surface_hits",
+                                           "normal_fetches", "uv_fetches", "color_fetches")])
 
 
 _lib = None
@@ -37,7 +39,7 @@ def lib():
         h.oracle_pathtrace.restype = C.c_int
         h.oracle_pathtrace.argtypes = [C.POINTER(_abi.SceneDesc), C.POINTER(_abi.PushConstants), C.c_uint32, C.c_uint32,
                                        C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
-                                       C.POINTER(OracleCounters), C.c_int]
+                                       C.POINTER(OracleCounters), C.c_int, C.c_int]
         h.oracle_trace_rays.restype = C.c_int
         h.oracle_trace_rays.argtypes = [C.POINTER(_abi.SceneDesc), C.c_uint32, C.c_void_p, C.c_void_p, C.c_float, C.c_uint32,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -48,6 +50,8 @@ def lib():
                                         C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         h.oracle_float_to_half.restype = C.c_uint16
         h.oracle_float_to_half.argtypes = [C.c_float]
+        h.oracle_float_to_half_rtz.restype = C.c_uint16
+        h.oracle_float_to_half_rtz.argtypes = [C.c_float]
         h.oracle_half_to_float.restype = C.c_float
         h.oracle_half_to_float.argtypes = [C.c_uint16]
         h.oracle_num_threads.restype = C.c_int
@@ -94,7 +98,8 @@ def dispatch_extent(width, height, tile_params=None):
 
 
 def pathtrace(scene, width, height, camera_params, camera_transform, max_bounces=8, samples_per_pixel=5, pathtrace_type=0,
-              accum_counter=0, prev_frame=None, advanced=None, tile_params=None, out=None, num_threads=0, want_f32=False):
+              accum_counter=0, prev_frame=None, advanced=None, tile_params=None, out=None, num_threads=0, want_f32=False,
+              store_rounding=0):
     """One pathtrace_scene call on the CPU.  Returns (rgba16f (H,W,4) float16, counters dict[, rgb f32])."""
     (ox, oy), gx, gy = dispatch_extent(width, height, tile_params)
     pc = push_constants(scene, camera_params, camera_transform, pathtrace_type, accum_counter, advanced, (ox, oy))
@@ -107,10 +112,13 @@ def pathtrace(scene, width, height, camera_params, camera_transform, max_bounces
         assert prev.shape == (height, width, 4)
     cnt = OracleCounters()
     rc = lib().oracle_pathtrace(C.byref(scene.desc), C.byref(pc), max_bounces, samples_per_pixel, width, height, gx, gy,
-                                _abi.ptr(prev), _abi.ptr(out), _abi.ptr(f32), C.byref(cnt), num_threads)
+                                _abi.ptr(prev), _abi.ptr(out), _abi.ptr(f32), C.byref(cnt), num_threads, store_rounding)
     if rc != 0:
         raise RuntimeError("oracle_pathtrace failed")
-    counters = {k: int(getattr(cnt, k)) for k, _ in OracleCounters._fields_}
+    counters = {}
+    for k, t in OracleCounters._fields_:
+        v = getattr(cnt, k)
+        counters[k] = int(v) if t is C.c_uint64 else [int(x) for x in v]   # 3-vectors: [extend, light-pdf, shadow]
     return (out, counters, f32) if want_f32 else (out, counters)
 
 

@@ -1,0 +1,164 @@
+"""Pins the CPU oracle (oracle/lupin_oracle.cpp) against the fixtures the reference itself holds:
+the furnace1 known-answer golden, its surviving golden renders (statistically: they are ~1000 spp,
+RGBE-quantised, produced with the author's device BVH), and first-principles checks of the pieces with
+closed forms (RNG recurrence, f16 conversion, tiling == full dispatch, the frame-0 accumulation quirk)."""
+import numpy as np
+import pytest
+
+from lupinpathtracer_amd import api, loader
+from oracle import oracle
+from tests import util
+
+
+def test_rng_stream_matches_pcg_recurrence(built):
+    """pathtracer.wgsl:1563-1600 restated independently in numpy integer arithmetic."""
+    def hash_u32(x):
+        x = np.uint64(x)
+        M = np.uint64(0xFFFFFFFF)
+        x ^= x >> np.uint64(17); x = (x * np.uint64(0xed5ad4bb)) & M
+        x ^= x >> np.uint64(11); x = (x * np.uint64(0xac4c1b51)) & M
+        x ^= x >> np.uint64(15); x = (x * np.uint64(0x31848bab)) & M
+        x ^= x >> np.uint64(14)
+        return int(x)
+    for gid, acc in [(0, 0), (12345, 0), (1024 * 511 + 7, 3), (0xFFFFFF, 200)]:
+        s = hash_u32(((gid * 19349663) & 0xFFFFFFFF) ^ ((acc * 83492791) & 0xFFFFFFFF))
+        want = []
+        for _ in range(16):
+            s = (s * 747796405 + 2891336453) & 0xFFFFFFFF
+            r = (((s >> ((s >> 28) + 4)) ^ s) * 277803737) & 0xFFFFFFFF
+            r = (r >> 22) ^ r
+            want.append(np.float32(r) / np.float32(4294967295.0))
+        got = oracle.rng_stream(gid, acc, 16)
+        assert np.array_equal(got, np.array(want, np.float32))
+        assert np.all((got >= 0) & (got <= 1))
+
+
+def test_half_conversion_matches_ieee(built):
+    lib = oracle.lib()
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([rng.normal(size=2000) * 10.0 ** rng.integers(-9, 5, 2000),
+                         [0.0, -0.0, 1.0, 65504.0, 65519.9, 65520.0, 1e9, 5.96e-8, 2.98e-8, 2.9802326e-08, 6.1e-5, np.inf, -np.inf]]).astype(np.float32)
+    for x in xs:
+        with np.errstate(over="ignore"):
+            want = np.float32(x).astype(np.float16).view(np.uint16)
+        assert lib.oracle_float_to_half(float(x)) == int(want), x
+    for h in list(range(0, 0x7C01, 97)) + [0x8000, 0xFBFF, 0x0001, 0x03FF, 0x0400]:
+        assert lib.oracle_half_to_float(h) == float(np.array([h], np.uint16).view(np.float16)[0])
+
+
+def test_furnace1_known_answer(built):
+    """White furnace: env emission 0.5, white rough conductor => 0.5 everywhere.
+    The reference's own golden decodes to mean 0.494 (RGBE truncation)."""
+    scene, cams = util.load_scene("furnace1")
+    cam = cams[0]
+    w, h = loader.compute_dimensions_for_1080p(cam.params.aspect)
+    assert (w, h) == (1920, 799)      # (1920.0 / 2.4000001) as u32
+    gold = loader.read_hdr(util.GOLDEN + "/renders/furnace1_cam0.hdr")
+    assert gold.shape == (799, 1920, 3)
+    assert abs(gold.mean() - 0.494) < 2e-3 and gold.max() <= 0.5
+    W, H = w // 8, h // 8
+    img = util.oracle_accumulate(scene, cam, W, H, frames=5, spp=8, advanced=api.AdvancedParams(max_radiance=10.0)).astype(np.float32)
+    rgb = img[..., :3]
+    assert abs(rgb.mean() - 0.5) < 0.01
+    assert abs(rgb.mean() - gold.mean()) < 0.012
+    # single samples of the one-sample mixture estimator can exceed 0.5 (weights up to 2x per bounce), so
+    # at 40 spp only the bulk is pinned; the 1000-spp golden tops out at 0.5 + RGBE quantisation
+    assert np.percentile(rgb, 99) < 0.56 and rgb.max() < 1.0
+    assert np.all(img[..., 3] == 1.0)
+
+
+GOLDEN_CASES = [("materials1", 1), ("materials4", 2), ("environments1", 1), ("arealights1", 2)]
+
+
+@pytest.mark.parametrize("name,cam_i", GOLDEN_CASES)
+def test_oracle_vs_reference_golden_renders(built, name, cam_i):
+    """The reference's golden `render_cam{N}.hdr`, replayed with lupin_tests' exact protocol
+    (lupin_tests/src/main.rs:29-35,125-138,163): 10 spp x 101 frames (accum_counter 0..100, f16 running average
+    with the frame-0 quirk), 8 bounces, Standard, max_radiance = 10 -- at 1/8 of the 1920-wide resolution.
+    Means must agree within 2 % (observed: 0.01 % .. 1.3 %) and 10x16-pixel block averages within 6 % relative RMSE (resolution differs 8x: edges and highlights alias).  The goldens were made
+    with the author's device BVH (most likely hardware ray query) and are RGBE-quantised, hence statistical.
+    Round-toward-zero f16 stores are what makes the means line up (nearest-even lands 1.8 % high)."""
+    scene, cams = util.load_scene(name)
+    cam = cams[cam_i]
+    small, full_shape, full_mean = util.golden_render(name, cam_i)
+    w, h = loader.compute_dimensions_for_1080p(cam.params.aspect)
+    assert (h, w) == tuple(full_shape)
+    W, H = w // 8, h // 8
+    adv = api.AdvancedParams(max_radiance=10.0)
+    img = util.oracle_accumulate(scene, cam, W, H, frames=101, spp=10, advanced=adv).astype(np.float32)[..., :3]
+    g = small[:H * 2, :W * 2].reshape(H, 2, W, 2, 3).mean(axis=(1, 3))
+    assert abs(img.mean() - g.mean()) / g.mean() < 0.02, (img.mean(), g.mean())
+    bh, bw = (H // 10) * 10, (W // 16) * 16
+    a = img[:bh, :bw].reshape(bh // 10, 10, bw // 16, 16, 3).mean(axis=(1, 3))
+    b = g[:bh, :bw].reshape(bh // 10, 10, bw // 16, 16, 3).mean(axis=(1, 3))
+    rel_rmse = np.sqrt(((a - b) ** 2).mean()) / g.mean()
+    assert rel_rmse < 0.06, rel_rmse
+
+
+def test_store_rounding_modes(built):
+    """RTZ (default, pinned by the goldens) vs RTE stores differ only in the last f16 bit, RTZ never above RTE."""
+    scene, cams = util.load_scene("cornellbox_builtin")
+    cam = cams[0]
+    a, _ = oracle.pathtrace(scene, 24, 24, cam.params, cam.transform, 4, 2, store_rounding=0)
+    b, _ = oracle.pathtrace(scene, 24, 24, cam.params, cam.transform, 4, 2, store_rounding=1)
+    d = b.view(np.uint16).astype(np.int32) - a.view(np.uint16).astype(np.int32)
+    assert d.min() >= 0 and d.max() == 1
+    lib = oracle.lib()
+    for x in [0.1, 0.3333, 1.0, 65519.0, 7e4, 1e-7, 6.2e-5]:
+        h = lib.oracle_float_to_half_rtz(x)
+        v = float(np.array([h], np.uint16).view(np.float16)[0])
+        assert v <= x and float(np.array([h + 1], np.uint16).view(np.float16)[0]) > x
+
+
+def test_tiled_dispatch_equals_full_dispatch(built):
+    """id_offset tiling (renderer.rs:807-829): pixels are independent, so the union of all tiles reproduces the
+    full-screen dispatch bit for bit (sizes chosen as multiples of 4: tiled mode floors edge remainders)."""
+    scene, cams = util.load_scene("cornellbox_builtin")
+    cam = cams[0]
+    W, H = 40, 24
+    full, _ = oracle.pathtrace(scene, W, H, cam.params, cam.transform, 4, 2)
+    out = np.zeros((H, W, 4), np.float16)
+    ts = 3
+    nt = api.get_num_tiles(ts, W, H)
+    assert nt == 8
+    for t in range(nt):
+        oracle.pathtrace(scene, W, H, cam.params, cam.transform, 4, 2, tile_params=api.TileParams(ts, t), out=out)
+    assert util.f16_words_differ(full, out) == 0
+
+
+def test_tiled_dispatch_skips_edge_remainder(built):
+    """renderer.rs:825-826: tiled mode dispatches floor((W - off)/4) groups, so a right/bottom remainder < 4 px
+    is never written; the full-screen path uses ceil + a bounds check."""
+    scene, cams = util.load_scene("cornellbox_builtin")
+    cam = cams[0]
+    W, H = 10, 9
+    out = np.zeros((H, W, 4), np.float16)
+    oracle.pathtrace(scene, W, H, cam.params, cam.transform, 2, 1, tile_params=api.TileParams(100, 0), out=out)
+    assert np.all(out[:8, :8, 3] == 1.0)
+    assert np.all(out[8:, :, 3] == 0.0) and np.all(out[:, 8:, 3] == 0.0)
+    full, _ = oracle.pathtrace(scene, W, H, cam.params, cam.transform, 2, 1)
+    assert np.all(full[..., 3] == 1.0)
+
+
+def test_accumulation_frame0_quirk_and_determinism(built):
+    """pathtracer.wgsl:279-285: weight = 1/accum_counter, so frame 1 fully replaces frame 0; and the render is a
+    pure function of (scene, pixel, accum_counter): thread count does not matter."""
+    scene, cams = util.load_scene("cornellbox_builtin")
+    cam = cams[0]
+    W = H = 32
+    f0, _ = oracle.pathtrace(scene, W, H, cam.params, cam.transform, 8, 4, accum_counter=0)
+    f1, _ = oracle.pathtrace(scene, W, H, cam.params, cam.transform, 8, 4, accum_counter=1, prev_frame=f0)
+    f1_alone, _ = oracle.pathtrace(scene, W, H, cam.params, cam.transform, 8, 4, accum_counter=1, prev_frame=np.zeros_like(f0))
+    assert util.f16_words_differ(f1, f1_alone) == 0
+    assert util.f16_words_differ(f0, f1) > 0
+    a, ca = oracle.pathtrace(scene, W, H, cam.params, cam.transform, 8, 4, num_threads=1)
+    b, cb = oracle.pathtrace(scene, W, H, cam.params, cam.transform, 8, 4, num_threads=5)
+    assert util.f16_words_differ(a, b) == 0 and ca == cb
+    assert ca["paths"] == W * H * 4 and ca["path_bounces"] >= ca["paths"]
+
+
+def test_empty_scene_renders_black(built):
+    scene = loader.build_scene_empty(None)
+    img, cnt = oracle.pathtrace(scene, 8, 8, api.CameraParams(), api.identity_mat3x4(), 8, 2)
+    assert np.all(img[..., :3] == 0) and np.all(img[..., 3] == 1)
+    assert cnt["closest_hit_queries"] == 0

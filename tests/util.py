@@ -1,0 +1,60 @@
+"""Shared helpers for the test-suite (fixtures live under tests/golden/, see make_fixtures.py)."""
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+SCENES = os.path.join(GOLDEN, "scenes")
+SHARED = os.path.join(SCENES, "_shared")
+
+_scene_cache = {}
+
+
+def load_scene(name, ctx=None):
+    """(Scene, cameras) for a fixture scene; host-side preprocessing is cached per (name, ctx is None)."""
+    from lupinpathtracer_amd import loader
+    key = (name, id(ctx) if ctx is not None else None)
+    if key not in _scene_cache:
+        if name == "cornellbox_builtin":
+            _scene_cache[key] = loader.build_scene_cornell_box(ctx)
+        else:
+            path = os.path.join(SCENES, name, name + ".json")
+            _scene_cache[key] = loader.load_scene_yoctogl_v24(path, ctx, asset_dirs=[SHARED])
+    return _scene_cache[key]
+
+
+def golden_render(name, cam):
+    """Downsampled (4x4 box) reference golden render and its full-size mean."""
+    z = np.load(os.path.join(GOLDEN, "renders", f"{name}_cam{cam}.npz"))
+    return z["small"].astype(np.float32), z["full_shape"], z["full_mean"]
+
+
+def f16_words_differ(a, b):
+    return int((np.ascontiguousarray(a).view(np.uint16) != np.ascontiguousarray(b).view(np.uint16)).sum())
+
+
+def oracle_accumulate(scene, cam, width, height, frames, spp, max_bounces=8, ptype=0, advanced=None, start=0):
+    """example1.rs:37-52 on the CPU oracle: frames accum_counter = start..start+frames-1, f16 running average."""
+    from oracle import oracle
+    prev = np.zeros((height, width, 4), np.float16)
+    out = prev
+    for k in range(start, start + frames):
+        out, _ = oracle.pathtrace(scene, width, height, cam.params, cam.transform, max_bounces, spp, ptype,
+                                  accum_counter=k, prev_frame=prev, advanced=advanced)
+        prev = out
+    return out
+
+
+def gpu_accumulate(ctx, scene, cam, width, height, frames, spp, max_bounces=8, ptype=0, advanced=None, start=0):
+    """The same loop through the C ABI (DoubleBufferedTexture + pathtrace_scene + flip)."""
+    from lupinpathtracer_amd import api
+    res = api.build_pathtrace_resources(ctx, api.BakedPathtraceParams(max_bounces=max_bounces, samples_per_pixel=spp))
+    out = api.DoubleBufferedTexture(ctx, width, height)
+    for k in range(start, start + frames):
+        desc = api.PathtraceDesc(accum_params=api.AccumulationParams(out.back(), k), camera_params=cam.params,
+                                 camera_transform=cam.transform, advanced=advanced or api.AdvancedParams())
+        api.pathtrace_scene(ctx, res, scene, out.front(), ptype, desc)
+        out.flip()
+    out.flip()
+    return out.front().download()
