@@ -396,6 +396,11 @@ int lupin_hip_trace_rays(LupinContext *ctx, const LupinScene *scene, uint32_t n,
                          uint32_t *out_hit, float *out_dst, float *out_uv,
                          uint32_t *out_instance, uint32_t *out_tri);
 
+/* Evaluates one function of include/lupin_detmath.h (fn: 0 sin, 1 cos, 2 atan, 3 atan2(x,y), 4 acos,
+ * 5 exp, 6 log, 7 pow(x,y), 8 x/y, 9 sqrt) on the device over host arrays; the tests require the
+ * result to be bit-identical to the host build of the same header. */
+int lupin_hip_detmath_probe(LupinContext *ctx, int fn, uint32_t n, const float *x, const float *y, float *out);
+
 /* Tile-sharded multi-GPU support: pack the pixels of every tile t with t % world == rank (tiles
  * of tile_size*4 pixels, row-major tile order as renderer.rs:816-817) into a dense device
  * buffer / scatter a packed buffer back. Payload layout: tiles in ascending t, each tile

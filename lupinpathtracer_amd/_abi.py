@@ -162,6 +162,7 @@ SYMBOLS = [
     ("lupin_hip_stats_reset", C.c_int, [_P, C.c_int]),
     ("lupin_hip_stats_get", C.c_int, [_P, C.POINTER(StatsC)]),
     ("lupin_hip_trace_rays", C.c_int, [_P, _P, _U32, _P, _P, C.c_float, _P, _P, _P, _P, _P]),
+    ("lupin_hip_detmath_probe", C.c_int, [_P, C.c_int, _U32, _P, _P, _P]),
     ("lupin_hip_pack_tiles", C.c_int, [_P, _P, _U32, _U32, _U32, _P, C.POINTER(C.c_uint64)]),
     ("lupin_hip_unpack_tiles", C.c_int, [_P, _P, _U32, _U32, _U32, _P]),
     ("lupin_hip_packed_tile_pixels", C.c_uint64, [_U32, _U32, _U32, _U32, _U32]),

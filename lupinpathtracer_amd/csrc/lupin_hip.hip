@@ -597,6 +597,29 @@ __global__ void __launch_bounds__(LP_BLOCK) k_trace(SceneDev sc, uint32_t n, con
     out_tri[i] = hit ? (c.tri - sc.meshes[sc.instances[c.inst].mesh_idx].tri_offset) : 0u;
 }
 
+// lupin_detmath.h evaluated on the device (tests compare it bit for bit with the host build)
+__global__ void __launch_bounds__(LP_BLOCK) k_detmath(int fn, uint32_t n, const float *x, const float *y, float *out)
+{
+    uint32_t i = blockIdx.x * LP_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float a = x[i], b = y[i], r;
+    switch (fn)
+    {
+    case 0: r = lpm_sinf(a); break;
+    case 1: r = lpm_cosf(a); break;
+    case 2: r = lpm_atanf(a); break;
+    case 3: r = lpm_atan2f(a, b); break;
+    case 4: r = lpm_acosf(a); break;
+    case 5: r = lpm_expf(a); break;
+    case 6: r = lpm_logf(a); break;
+    case 7: r = lpm_powf(a, b); break;
+    case 8: r = a / b; break;
+    case 9: r = sqrtf(a); break;
+    default: r = 0.0f; break;
+    }
+    out[i] = r;
+}
+
 // tile pack / unpack for the multi-GPU gather: tiles t = rank, rank+world, ... in row-major tile order
 __global__ void __launch_bounds__(LP_BLOCK) k_pack_tiles(const uint2 *tex, uint2 *packed, uint32_t width, uint32_t height,
                                                          uint32_t tile_px, uint32_t rank, uint32_t world, int unpack)
@@ -1433,6 +1456,24 @@ int lupin_hip_trace_rays(LupinContext *ctx, const LupinScene *scene, uint32_t n,
     HIP_TRY(hipMemcpyAsync(out_tri, d_tri, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     hipFree(d_ori); hipFree(d_dir); hipFree(d_dst); hipFree(d_uv); hipFree(d_hit); hipFree(d_inst); hipFree(d_tri);
+    return LUPIN_OK;
+}
+
+int lupin_hip_detmath_probe(LupinContext *ctx, int fn, uint32_t n, const float *x, const float *y, float *out)
+{
+    if (!ctx || !x || !y || !out) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return LUPIN_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    float *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc((void **)&dx, (size_t)n * 4));
+    HIP_TRY(hipMalloc((void **)&dy, (size_t)n * 4));
+    HIP_TRY(hipMalloc((void **)&dout, (size_t)n * 4));
+    HIP_TRY(hipMemcpyAsync(dx, x, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dy, y, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_detmath, dim3((n + LP_BLOCK - 1) / LP_BLOCK), dim3(LP_BLOCK), 0, ctx->stream, fn, n, dx, dy, dout);
+    HIP_TRY(hipMemcpyAsync(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    hipFree(dx); hipFree(dy); hipFree(dout);
     return LUPIN_OK;
 }
 
