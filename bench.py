@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Msamples/s (path-bounces per second) of the HIP path tracer.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one `pathtrace_scene` accumulation frame (samples_per_pixel = 8, 8 bounces, Standard integrator) of
+the Cornell box -- BASELINE.json configs[1] (cornellbox 1024 x 1024, 8 bounces; its 1024 spp are 128 such
+frames, Msamples/s does not depend on how many are timed).  With N > 1 (one rank per GPU, torch.distributed
+over RCCL) the image grows with N (weak scaling: 1024^2 pixels per GPU) and its tiles are dealt round-robin to
+the ranks; no collective runs while accumulating, the timed region ends with the one all-gather of tile
+payloads that a readback needs.
+
+The JSON line also carries
+  roofline      algorithmic bytes (oracle work counters, tests/golden/work_counters.json) of the dominant kernel
+                divided by its hipEvent-measured duration, against the 8 TB/s HBM3E peak;
+  cpu_baseline  the CPU oracle (a restatement of the reference megakernel -- the reference has no CPU path) on one
+                full step of the same workload on this host's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def image_size_for(n_gpus, base):
+    """base^2 pixels per GPU: 1 -> 1x1, 2 -> 2x1, 4 -> 2x2, 8 -> 4x2 blocks of base x base."""
+    bx = 1
+    while bx * bx < n_gpus:
+        bx *= 2
+    by = max(1, n_gpus // bx)
+    while bx * by < n_gpus:
+        by += 1
+    return base * bx, base * by
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--size", type=int, default=1024, help="pixels per side per GPU")
+    ap.add_argument("--spp", type=int, default=8, help="samples per pixel per step (baked)")
+    ap.add_argument("--bounces", type=int, default=8)
+    ap.add_argument("--tile-size", type=int, default=32, help="tile edge in 4-px workgroups for multi-GPU sharding")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel hipEvent pass (roofline = null)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import numpy as np
+    from lupinpathtracer_amd import api, loader, distributed
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    ctx = api.Context(local_rank)
+    scene, cams = loader.build_scene_cornell_box(ctx)
+    cam = cams[0]
+    W, H = image_size_for(world, args.size)
+    cam_params = api.CameraParams(**{**cam.params.__dict__, "aspect": cam.params.aspect * W / H})
+    res = api.build_pathtrace_resources(ctx, api.BakedPathtraceParams(max_bounces=args.bounces, samples_per_pixel=args.spp))
+    out = api.DoubleBufferedTexture(ctx, W, H)
+    ptype = api.PathtraceType.Standard
+
+    frame = [0]
+
+    def step():
+        desc = api.PathtraceDesc(accum_params=api.AccumulationParams(out.back(), frame[0]), camera_params=cam_params,
+                                 camera_transform=cam.transform)
+        if world == 1:
+            api.pathtrace_scene(ctx, res, scene, out.front(), ptype, desc)
+        else:
+            api.pathtrace_scene_tiles(ctx, res, scene, out.front(), ptype, desc, args.tile_size, rank, world)
+        out.flip()
+        frame[0] += 1
+
+    def full_sync():
+        ctx.sync()
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    ops = distributed.HipTileOps(torch, ctx, device)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:   # warm the collective too
+        out.flip()
+        distributed.gather_framebuffer(dist, ops, out.front(), W, H, args.tile_size, rank, world)
+        out.flip()
+    full_sync()
+    ctx.stats_reset(False)
+
+    # ---- timed region: exactly K steps + the readback gather ----
+    full_sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        out.flip()   # front = last rendered frame
+        distributed.gather_framebuffer(dist, ops, out.front(), W, H, args.tile_size, rank, world)
+        out.flip()
+    full_sync()
+    elapsed = time.perf_counter() - t0
+
+    st = ctx.stats()
+    units = torch.tensor([float(st["path_bounces"]), float(st["paths"])], dtype=torch.float64, device=device)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(units, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    total_units, total_paths, elapsed = float(units[0]), float(units[1]), float(tmax[0])
+
+    # ---- per-kernel pass (rank 0, N = 1): hipEvents around every extend / shade launch, on the kernels' stream ----
+    roofline = None
+    kernel_ms = None
+    if rank == 0 and world == 1 and not args.no_kernel_timing:
+        ksteps = min(args.steps, 8)
+        ctx.stats_reset(True)
+        for _ in range(ksteps):
+            step()
+        kst = ctx.stats()
+        ctx.stats_reset(False)
+        with open(os.path.join(ROOT, "tests", "golden", "work_counters.json")) as f:
+            wc = json.load(f)
+        key = f"cornellbox_1024x1024_b{args.bounces}_spp{args.spp}_standard"
+        if key in wc and args.size == 1024 and kst["extend_launches"] > 0:
+            launches = kst["extend_launches"]
+            kernel_ms = {"extend": kst["extend_ms"], "shade": kst["shade_ms"], "total": kst["total_ms"], "launches": launches,
+                         "steps": ksteps}
+            name = "k_shade" if kst["shade_ms"] >= kst["extend_ms"] else "k_extend"
+            per_unit = wc[key]["shade_bytes_per_unit" if name == "k_shade" else "extend_bytes_per_unit"]
+            ms = kst["shade_ms"] if name == "k_shade" else kst["extend_ms"]
+            bytes_per_launch = per_unit * kst["path_bounces"] / launches
+            avg_launch_s = ms * 1e-3 / launches
+            achieved = bytes_per_launch / avg_launch_s / 1e9
+            roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "bytes_per_unit": per_unit, "units_per_launch": kst["path_bounces"] / launches,
+                        "avg_launch_us": avg_launch_s * 1e6,
+                        "note": "algorithmic bytes in the reference's layout; scene is cache-resident, HBM traffic itself is far lower"}
+
+    # ---- CPU baseline (rank 0, N = 1): one full step of the same workload on the oracle ----
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle
+        host_scene, host_cams = loader.build_scene_cornell_box(None)
+        hc = host_cams[0]
+        threads = oracle.num_threads()
+        side = args.size
+        oracle.pathtrace(host_scene, 64, 64, hc.params, hc.transform, args.bounces, 1)   # page the library in
+        c0 = time.perf_counter()
+        _, cnt = oracle.pathtrace(host_scene, side, side, hc.params, hc.transform, args.bounces, args.spp)
+        cdt = time.perf_counter() - c0
+        cpu_baseline = {"value": cnt["path_bounces"] / cdt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
+                        "sample": f"1 step: cornellbox {side}x{side}, {args.bounces} bounces, {args.spp} spp "
+                                  f"({cnt['path_bounces']} path-bounces, {cdt:.2f} s, OpenMP over rows)"}
+
+    if rank == 0:
+        value = total_units / elapsed / 1e6
+        line = {
+            "metric": "Msamples/sec (paths x bounces)", "value": value, "unit": "Msamples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cornellbox {W}x{H} ({args.size}^2 px per GPU), {args.bounces} bounces, "
+                                   f"{args.spp} spp per step, Standard integrator, software BVH",
+                       "scene": "built-in Cornell box (8 instances, 36 triangles, 1 area light)",
+                       "samples_per_pixel_per_step": args.spp, "spp_total_timed": args.spp * args.steps,
+                       "sharding": "single dispatch" if world == 1 else f"tile-sharded, tile {args.tile_size * 4}px, round-robin, RCCL all-gather at readback"},
+            "Mpaths_per_s": total_paths / elapsed / 1e6,
+            "path_bounces": total_units,
+            "roofline": roofline, "kernel_ms": kernel_ms, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,112 @@
+"""Tile-sharded rendering across the GPUs of one node.
+
+The path shards by pixel tiles: every pixel owns its RNG stream (seeded from the GLOBAL pixel index and
+accum_counter, pathtracer.wgsl:224-226) and its output texel, so ranks never exchange anything while
+accumulating.  Tiles (tile_size x 4 pixels, numbered row-major like renderer.rs:816-817) are dealt
+round-robin, rank r owns tiles r, r + world, ... -- interleaved because per-tile cost varies a lot (sky vs
+geometry).  The one exchange step is the gather of per-tile Rgba16Float payloads at readback: one all-gather of
+equally sized packed buffers (RCCL over xGMI on the GPU box; gloo in the CPU tests).
+
+`TileDeviceOps` is the seam between this host logic and the device: the product implementation calls the HIP
+pack / unpack kernels of the C ABI; tests substitute a numpy implementation to exercise the same code over gloo.
+"""
+import numpy as np
+
+WORKGROUP_SIZE = 4
+
+
+def tile_grid(width, height, tile_size):
+    tpx = tile_size * WORKGROUP_SIZE
+    return (max(1, width) - 1) // tpx + 1, (max(1, height) - 1) // tpx + 1, tpx
+
+
+def owned_tiles(width, height, tile_size, rank, world):
+    ntx, nty, _ = tile_grid(width, height, tile_size)
+    return list(range(rank, ntx * nty, world))
+
+
+def tile_rect(width, height, tile_size, t):
+    ntx, nty, tpx = tile_grid(width, height, tile_size)
+    ox, oy = (t % ntx) * tpx, (t // ntx) * tpx
+    return ox, oy, min(tpx, width - ox), min(tpx, height - oy)
+
+
+def packed_pixels(width, height, tile_size, rank, world):
+    return sum(w * h for (_, _, w, h) in (tile_rect(width, height, tile_size, t) for t in owned_tiles(width, height, tile_size, rank, world)))
+
+
+def pack_tiles_numpy(image, tile_size, rank, world):
+    """Reference layout of the packed payload: owned tiles in ascending order, each tile row-major, 8 B per pixel.
+    image: (H, W, 4) float16.  (The HIP kernel k_pack_tiles produces exactly this.)"""
+    h, w = image.shape[:2]
+    parts = []
+    for t in owned_tiles(w, h, tile_size, rank, world):
+        ox, oy, tw, th = tile_rect(w, h, tile_size, t)
+        parts.append(image[oy:oy + th, ox:ox + tw].reshape(-1, 4))
+    return np.concatenate(parts, axis=0) if parts else np.zeros((0, 4), image.dtype)
+
+
+def unpack_tiles_numpy(image, packed, tile_size, rank, world):
+    h, w = image.shape[:2]
+    pos = 0
+    for t in owned_tiles(w, h, tile_size, rank, world):
+        ox, oy, tw, th = tile_rect(w, h, tile_size, t)
+        image[oy:oy + th, ox:ox + tw] = packed[pos:pos + tw * th].reshape(th, tw, 4)
+        pos += tw * th
+    return image
+
+
+class NumpyTileOps:
+    """Test double for the device side: framebuffers are (H, W, 4) float16 numpy arrays."""
+
+    def __init__(self, torch):
+        self.torch = torch
+
+    def pack(self, image, tile_size, rank, world, capacity_pixels):
+        p = pack_tiles_numpy(image, tile_size, rank, world)
+        buf = np.zeros((capacity_pixels, 4), np.float16)
+        buf[:len(p)] = p
+        return self.torch.from_numpy(buf.view(np.int64).reshape(-1).copy())   # one int64 word per Rgba16Float pixel
+
+    def unpack(self, image, payload, tile_size, rank, world):
+        packed = payload.contiguous().numpy().view(np.float16).reshape(-1, 4)
+        unpack_tiles_numpy(image, packed, tile_size, rank, world)
+
+
+class HipTileOps:
+    """Product implementation: payloads are torch CUDA tensors, pack / unpack run as HIP kernels on the
+    context's stream (lupin_hip_pack_tiles / lupin_hip_unpack_tiles)."""
+
+    def __init__(self, torch, ctx, device):
+        self.torch, self.ctx, self.device = torch, ctx, device
+
+    def pack(self, texture, tile_size, rank, world, capacity_pixels):
+        from . import api
+        buf = self.torch.zeros(capacity_pixels, dtype=self.torch.int64, device=self.device)   # 8 B per pixel
+        self.torch.cuda.synchronize(self.device)            # the zero fill runs on torch's stream
+        api.pack_tiles(self.ctx, texture, tile_size, rank, world, buf.data_ptr())
+        self.ctx.sync()                                     # payload complete before the collective reads it
+        return buf
+
+    def unpack(self, texture, payload, tile_size, rank, world):
+        from . import api
+        api.unpack_tiles(self.ctx, texture, tile_size, rank, world, payload.data_ptr())
+        self.ctx.sync()
+
+
+def gather_framebuffer(dist, ops, framebuffer, width, height, tile_size, rank, world):
+    """All-gather the per-rank tile payloads and scatter them into `framebuffer` on every rank.
+    Returns the number of payload bytes this rank contributed."""
+    capacity = max(packed_pixels(width, height, tile_size, r, world) for r in range(world))
+    mine = ops.pack(framebuffer, tile_size, rank, world, capacity)
+    if world == 1:
+        return capacity * 8
+    torch = ops.torch
+    gathered = torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device)
+    dist.all_gather_into_tensor(gathered, mine)
+    if mine.is_cuda:
+        torch.cuda.synchronize(mine.device)
+    for r in range(world):
+        if r != rank:
+            ops.unpack(framebuffer, gathered[r * mine.numel():(r + 1) * mine.numel()], tile_size, r, world)
+    return capacity * 8
