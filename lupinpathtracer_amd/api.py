@@ -158,9 +158,9 @@ class PathtraceResources:
 
     def __del__(self):
         try:
-            if self.handle:
+            if self.handle and self.ctx.handle:   # a closed context has already released the device
                 lib().lupin_hip_destroy_pathtrace_resources(self.handle)
-                self.handle = None
+            self.handle = None
         except Exception:
             pass
 
@@ -202,9 +202,9 @@ class Texture:
 
     def __del__(self):
         try:
-            if self._owned and self.handle:
+            if self._owned and self.handle and self.ctx.handle:
                 lib().lupin_hip_texture_destroy(self.handle)
-                self.handle = None
+            self.handle = None
         except Exception:
             pass
 
@@ -239,9 +239,9 @@ class DoubleBufferedTexture:
 
     def __del__(self):
         try:
-            if self.handle:
+            if self.handle and self.ctx.handle:
                 lib().lupin_hip_dbuf_destroy(self.handle)
-                self.handle = None
+            self.handle = None
         except Exception:
             pass
 
@@ -442,9 +442,9 @@ class Scene:
 
     def __del__(self):
         try:
-            if self.handle:
+            if self.handle and self.ctx is not None and self.ctx.handle:
                 lib().lupin_hip_scene_destroy(self.handle)
-                self.handle = None
+            self.handle = None
         except Exception:
             pass
 
