@@ -190,14 +190,17 @@ LP_DEV uint32_t rnd_range(uint32_t &s, uint32_t max_exclusive)
 // Intersection primitives (pathtracer.wgsl:2906-2943)
 // ------------------------------------------------------------------------------------------------
 
+// Slab test (pathtracer.wgsl:2906-2917).  min/max here are IEEE minNum/maxNum (v_min_f32 / v_max_f32 /
+// v_min3 / v_max3 on gfx950, fminf/fmaxf in the oracle): WGSL lets min/max return either operand when one is
+// NaN, and the results only feed comparisons, so the sign of a zero is immaterial.
 LP_DEV float slab_dst(f3 o, f3 inv_d, float lox, float loy, float loz, float hix, float hiy, float hiz)
 {
     float tminx = (lox - o.x) * inv_d.x, tminy = (loy - o.y) * inv_d.y, tminz = (loz - o.z) * inv_d.z;
     float tmaxx = (hix - o.x) * inv_d.x, tmaxy = (hiy - o.y) * inv_d.y, tmaxz = (hiz - o.z) * inv_d.z;
-    float t1x = minf(tminx, tmaxx), t1y = minf(tminy, tmaxy), t1z = minf(tminz, tmaxz);
-    float t2x = maxf(tminx, tmaxx), t2y = maxf(tminy, tmaxy), t2z = maxf(tminz, tmaxz);
-    float dst_far = minf(minf(t2x, t2y), t2z);
-    float dst_near = maxf(maxf(t1x, t1y), t1z);
+    float t1x = __builtin_fminf(tminx, tmaxx), t1y = __builtin_fminf(tminy, tmaxy), t1z = __builtin_fminf(tminz, tmaxz);
+    float t2x = __builtin_fmaxf(tminx, tmaxx), t2y = __builtin_fmaxf(tminy, tmaxy), t2z = __builtin_fmaxf(tminz, tmaxz);
+    float dst_far = __builtin_fminf(__builtin_fminf(t2x, t2y), t2z);
+    float dst_near = __builtin_fmaxf(__builtin_fmaxf(t1x, t1y), t1z);
     bool did_hit = dst_far >= dst_near && dst_far > 0.0f;
     return did_hit ? dst_near : LP_F32_MAX;
 }
@@ -284,54 +287,87 @@ LP_DEV bool blas_closest(const SceneDev &sc, uint32_t *stack, uint32_t sp_base, 
     return replaced;
 }
 
-// ray_scene_intersection (bvh_custom.wgsl:7-110): TLAS walk, instance entry, BLAS walk.
+// ray_scene_intersection (bvh_custom.wgsl:7-110) as ONE convergent loop over both levels.
+//
+// The reference nests the BLAS loop inside the TLAS loop; compiled as written, lanes that are between
+// instances idle while their neighbours finish a BLAS.  Here TLAS and BLAS internal nodes share one
+// code path (same 64-byte node format, only the ray and the node array differ by level), and the
+// loop is organised "while-while": every lane first descends through internal nodes of either level
+// until it holds a leaf, then the wave handles leaves (instance entry / triangles) together.
+// Visiting order per lane is unchanged, so results are identical to the nested form.
 LP_DEV Closest scene_closest(const SceneDev &sc, uint32_t *stack, f3 o, f3 d, float eps)
 {
     const uint32_t tid = threadIdx.x;
+    constexpr uint32_t REF_DONE = 0xFFFFFFFFu;   // not a valid leaf reference (leaf payloads are < 2^31 - 1)
     Closest best;
     best.t = LP_F32_MAX; best.u = 0.0f; best.v = 0.0f; best.tri = 0u; best.inst = 0xFFFFFFFFu;
     if (sc.num_instances == 0) return best;
-    f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+
+    f3 co = o, cd = d, cinv = inv_d;       // ray of the current level (world, or instance-local)
+    const WideNode *nodes = sc.tlas;
     uint32_t sp = 0;
+    uint32_t blas_base = 0xFFFFFFFFu;      // stack height at instance entry; all-ones = at TLAS level
+    uint32_t cur_inst = 0;
     uint32_t cur = sc.tlas_root;
+
+    // pop the next reference; leaving an exhausted BLAS restores the world ray and keeps popping the TLAS part
+    auto pop = [&]() {
+        if (sp == blas_base) { blas_base = 0xFFFFFFFFu; co = o; cd = d; cinv = inv_d; nodes = sc.tlas; }
+        if (sp == 0) { cur = REF_DONE; return; }
+        sp--;
+        cur = stack[sp * LP_BLOCK + tid];
+    };
+
     for (;;)
     {
-        if (cur & REF_LEAF)
+        // ---- phase 1: internal nodes of either level ----
+        while (!(cur & REF_LEAF))
         {
-            uint32_t ii = cur & ~REF_LEAF;
-            const InstanceDev in = sc.instances[ii];
-            // vec4(ori,1) * transpose_inverse_transform and vec4(dir,0) * ... (bvh_custom.wgsl:30-35)
-            f3 lo = mk3(o.x * in.r0.x + o.y * in.r0.y + o.z * in.r0.z + 1.0f * in.r0.w,
-                        o.x * in.r1.x + o.y * in.r1.y + o.z * in.r1.z + 1.0f * in.r1.w,
-                        o.x * in.r2.x + o.y * in.r2.y + o.z * in.r2.z + 1.0f * in.r2.w);
-            f3 ld = mk3(d.x * in.r0.x + d.y * in.r0.y + d.z * in.r0.z + 0.0f * in.r0.w,
-                        d.x * in.r1.x + d.y * in.r1.y + d.z * in.r1.z + 0.0f * in.r1.w,
-                        d.x * in.r2.x + d.y * in.r2.y + d.z * in.r2.z + 0.0f * in.r2.w);
-            f3 linv = mk3(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
-            if (blas_closest(sc, stack, sp, in.blas_root, lo, ld, linv, eps, best)) best.inst = ii;
-            if (sp == 0) break;
-            sp--;
-            cur = stack[sp * LP_BLOCK + tid];
-        }
-        else
-        {
-            const WideNode nd = sc.tlas[cur];
-            float ldst = slab_dst(o, inv_d, nd.a.x, nd.a.y, nd.a.z, nd.a.w, nd.b.x, nd.b.y);
-            float rdst = slab_dst(o, inv_d, nd.b.z, nd.b.w, nd.c.x, nd.c.y, nd.c.z, nd.c.w);
-            bool left_first = ldst <= rdst;
-            bool push_l = ldst < best.t, push_r = rdst < best.t;
+            const WideNode nd = nodes[cur];
+            float ld = slab_dst(co, cinv, nd.a.x, nd.a.y, nd.a.z, nd.a.w, nd.b.x, nd.b.y);
+            float rd = slab_dst(co, cinv, nd.b.z, nd.b.w, nd.c.x, nd.c.y, nd.c.z, nd.c.w);
+            bool left_first = ld <= rd;
+            bool push_l = ld < best.t, push_r = rd < best.t;
             uint32_t near_ref = left_first ? nd.d.x : nd.d.y;
             uint32_t far_ref = left_first ? nd.d.y : nd.d.x;
             bool push_near = left_first ? push_l : push_r;
             bool push_far = left_first ? push_r : push_l;
             if (push_far) { stack[sp * LP_BLOCK + tid] = far_ref; sp++; }
-            if (push_near) { cur = near_ref; }
-            else
+            if (push_near) cur = near_ref; else pop();
+        }
+        if (cur == REF_DONE) break;
+
+        // ---- phase 2: leaves ----
+        if (blas_base == 0xFFFFFFFFu)
+        {
+            // TLAS leaf: enter the instance (bvh_custom.wgsl:28-37)
+            cur_inst = cur & ~REF_LEAF;
+            const InstanceDev in = sc.instances[cur_inst];
+            co = mk3(o.x * in.r0.x + o.y * in.r0.y + o.z * in.r0.z + 1.0f * in.r0.w,
+                     o.x * in.r1.x + o.y * in.r1.y + o.z * in.r1.z + 1.0f * in.r1.w,
+                     o.x * in.r2.x + o.y * in.r2.y + o.z * in.r2.z + 1.0f * in.r2.w);
+            cd = mk3(d.x * in.r0.x + d.y * in.r0.y + d.z * in.r0.z + 0.0f * in.r0.w,
+                     d.x * in.r1.x + d.y * in.r1.y + d.z * in.r1.z + 0.0f * in.r1.w,
+                     d.x * in.r2.x + d.y * in.r2.y + d.z * in.r2.z + 0.0f * in.r2.w);
+            cinv = mk3(1.0f / cd.x, 1.0f / cd.y, 1.0f / cd.z);
+            nodes = sc.blas;
+            blas_base = sp;
+            cur = in.blas_root;
+        }
+        else
+        {
+            // BLAS leaf: its triangles, first-found wins ties (strict <)
+            uint32_t ti = cur & ~REF_LEAF;
+            for (;;)
             {
-                if (sp == 0) break;
-                sp--;
-                cur = stack[sp * LP_BLOCK + tid];
+                const TriVerts tv = sc.tris[ti];
+                TriHit h = tri_dst(co, cd, xyz(tv.v0), xyz(tv.v1), xyz(tv.v2), eps);
+                if (h.t < best.t) { best.t = h.t; best.u = h.u; best.v = h.v; best.tri = ti; best.inst = cur_inst; }
+                if (__float_as_uint(tv.v0.w) & LEAF_END_BITS) break;
+                ti++;
             }
+            pop();
         }
     }
     return best;

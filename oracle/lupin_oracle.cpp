@@ -14,7 +14,8 @@
 // Choices where WGSL leaves behaviour to the driver (stated in DESIGN.md):
 //   * transcendentals = include/lupin_detmath.h (correctly rounded f32);
 //   * dot/cross/matrix products are summed left to right, no FMA contraction;
-//   * min(a,b) = b<a ? b : a, max(a,b) = a<b ? b : a (GLSL.std.450 FMin/FMax on ordered input);
+//   * min(a,b) = b<a ? b : a, max(a,b) = a<b ? b : a (GLSL.std.450 FMin/FMax on ordered input), except in
+//     the ray/box slab test, where they are IEEE minNum/maxNum (the hardware min/max of the target);
 //   * normalize(v) = v / sqrt(dot(v,v)); mix(a,b,t) = a*(1-t) + b*t;
 //   * pow(x, 2.0) is x*x (what every Vulkan compiler folds it to; pow of a negative base is
 //     otherwise undefined in WGSL) -- pathtracer.wgsl:2067,2190;
@@ -317,10 +318,12 @@ struct Inv
     {
         vec3f t_min = (aabb_min - ray.ori) * ray.inv_dir;
         vec3f t_max = (aabb_max - ray.ori) * ray.inv_dir;
-        vec3f t1 = min3(t_min, t_max);
-        vec3f t2 = max3(t_min, t_max);
-        float dst_far = fmin_(fmin_(t2.x, t2.y), t2.z);
-        float dst_near = fmax_(fmax_(t1.x, t1.y), t1.z);
+        // min/max of the slab test are IEEE minNum/maxNum (fminf/fmaxf): a NaN operand (0 * inf when a ray
+        // with a zero direction component starts on a box plane) yields the other operand
+        vec3f t1 = {fminf(t_min.x, t_max.x), fminf(t_min.y, t_max.y), fminf(t_min.z, t_max.z)};
+        vec3f t2 = {fmaxf(t_min.x, t_max.x), fmaxf(t_min.y, t_max.y), fmaxf(t_min.z, t_max.z)};
+        float dst_far = fminf(fminf(t2.x, t2.y), t2.z);
+        float dst_near = fmaxf(fmaxf(t1.x, t1.y), t1.z);
         bool did_hit = dst_far >= dst_near && dst_far > 0.0f;
         return did_hit ? dst_near : F32_MAX;
     }
