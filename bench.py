@@ -64,7 +64,7 @@ def main():
     from lupinpathtracer_amd import api, loader, distributed
 
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("LUPIN_BENCH_FORCE_DIST") == "1":   # the flag exercises the N > 1 code path on one GPU
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -85,7 +85,7 @@ def main():
     def step():
         desc = api.PathtraceDesc(accum_params=api.AccumulationParams(out.back(), frame[0]), camera_params=cam_params,
                                  camera_transform=cam.transform)
-        if world == 1:
+        if dist is None:
             api.pathtrace_scene(ctx, res, scene, out.front(), ptype, desc)
         else:
             api.pathtrace_scene_tiles(ctx, res, scene, out.front(), ptype, desc, args.tile_size, rank, world)
@@ -103,7 +103,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if world > 1:   # warm the collective too
+    if dist is not None:   # warm the collective too
         out.flip()
         distributed.gather_framebuffer(dist, ops, out.front(), W, H, args.tile_size, rank, world)
         out.flip()
@@ -115,7 +115,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    if world > 1:
+    if dist is not None:
         out.flip()   # front = last rendered frame
         distributed.gather_framebuffer(dist, ops, out.front(), W, H, args.tile_size, rank, world)
         out.flip()

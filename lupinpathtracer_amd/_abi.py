@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblupin_hip.so")
+# LUPIN_HIP_LIB overrides the path (A/B runs of kernel variants); it is still the same C ABI, never a fallback
+LIB_PATH = os.environ.get("LUPIN_HIP_LIB") or os.path.join(_HERE, "liblupin_hip.so")
 
 SENTINEL_IDX = 0xFFFFFFFF
 

@@ -60,6 +60,7 @@ struct PathBuffers
     // always reads and appends shard b % LP_SHARDS, so a shard never grows beyond its initial size.
     uint32_t *queue[2];   // [parity][shard * shard_cap + i]
     uint32_t *counts;     // counts[k * LP_SHARDS + s] = live paths of shard s entering iteration k
+    uint32_t *heads;      // heads[k * LP_SHARDS + s]  = next unclaimed queue entry (persistent extend kernel)
     uint32_t shard_cap;   // slots per shard (multiple of LP_BLOCK)
 };
 
@@ -239,6 +240,196 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend(SceneDev sc, FrameParams fp
     pb.hit[slot] = make_float4(total, c.u, c.v, __uint_as_float(hit ? c.inst : HIT_MISS));
     pb.hit_tri[slot] = c.tri;
     if (rng != rng_in) pb.ori_rng[slot].w = __uint_as_float(rng);
+}
+
+
+// Persistent form of k_extend.  Rays of one wave need very different numbers of traversal steps (Cornell box:
+// 4 .. 25 node visits), so a one-ray-per-lane kernel keeps only ~36 % of the lanes busy (PMC: SQ_THREAD_CYCLES_VALU /
+// (SQ_ACTIVE_INST_VALU * 64)).  Here each wave owns its lanes for the whole launch and refills idle lanes whenever at
+// least LP_REFILL_MIN of them have finished.  Work is partitioned statically, so refilling needs no atomics: the
+// grid holds `wps` waves per shard, and wave j of shard s owns the 64-entry chunks j, j + wps, j + 2 wps, ... of that
+// shard's queue.  Every ray is still traced exactly as in k_extend, only by a different lane.
+constexpr uint32_t LP_REFILL_MIN = 16;
+
+template <int TYPE>
+__global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, FrameParams fp, PathBuffers pb, uint32_t iter,
+                                                                unsigned long long *shard_stats)
+{
+    extern __shared__ uint32_t lds_stack[];
+    static_assert(LP_SHARDS == LP_BLOCK, "block 0 books one shard per thread");
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t *counts = pb.counts + (size_t)iter * LP_SHARDS;
+    const uint32_t *queue = pb.queue[iter & 1];
+    if (blockIdx.x == 0) { const uint32_t c = counts[tid]; if (c) shard_stats[tid * 2 + 0] += c; }   // one writer per shard per launch
+
+    // this wave's share of the work
+    const uint32_t wave = blockIdx.x * (LP_BLOCK / 64) + tid / 64;         // wave-uniform
+    const uint32_t wps = (gridDim.x * (LP_BLOCK / 64)) / LP_SHARDS;         // waves per shard (grid is a multiple of 64 blocks)
+    const uint32_t shard = wave % LP_SHARDS, j = wave / LP_SHARDS;
+    const uint32_t cnt = counts[shard];
+    const uint32_t full_chunks = cnt / 64u;
+    uint32_t n_mine = (full_chunks > j) ? ((full_chunks - j - 1u) / wps + 1u) * 64u : 0u;
+    if ((cnt % 64u) && (full_chunks % wps) == j) n_mine += cnt % 64u;       // the partial last chunk
+    if (n_mine == 0) return;
+    const size_t shard_base = (size_t)shard * pb.shard_cap;
+    uint32_t next_pos = 0;                                                  // position in this wave's private sequence
+
+    const float eps = fp.pc.ray_epsilon;
+    constexpr uint32_t REF_DONE = 0xFFFFFFFFu;
+
+    // per-lane ray + traversal state
+    bool active = false;
+    uint32_t slot = 0, rng = 0, rng_in = 0, alpha_k = 0;
+    float total_dst = 0.0f;
+    f3 o = splat(0.0f), d = splat(0.0f), inv_d = splat(0.0f);
+    f3 co = o, cd = d, cinv = inv_d;
+    const WideNode *nodes = sc.tlas;
+    uint32_t sp = 0, blas_base = 0xFFFFFFFFu, cur_inst = 0, cur = REF_DONE;
+    Closest best;
+    best.t = LP_F32_MAX; best.u = 0.0f; best.v = 0.0f; best.tri = 0u; best.inst = HIT_MISS;
+
+    auto start_traversal = [&]() {
+        inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        co = o; cd = d; cinv = inv_d;
+        nodes = sc.tlas;
+        sp = 0; blas_base = 0xFFFFFFFFu;
+        cur = sc.num_instances ? sc.tlas_root : REF_DONE;
+        best.t = LP_F32_MAX; best.u = 0.0f; best.v = 0.0f; best.tri = 0u; best.inst = HIT_MISS;
+    };
+    auto pop = [&]() {
+        if (sp == blas_base) { blas_base = 0xFFFFFFFFu; co = o; cd = d; cinv = inv_d; nodes = sc.tlas; }
+        if (sp == 0) { cur = REF_DONE; return; }
+        sp--;
+        cur = lds_stack[sp * LP_BLOCK + tid];
+    };
+
+    for (;;)
+    {
+        // ---- refill idle lanes ----
+        const unsigned long long idle = __ballot(!active);
+        const uint32_t need = (uint32_t)__popcll(idle);
+        if (need >= LP_REFILL_MIN && next_pos < n_mine)
+        {
+            const uint32_t my_rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            const uint32_t take = min(need, n_mine - next_pos);
+            const bool got = !active && my_rank < take;
+            const uint32_t pos = next_pos + my_rank;
+            const size_t q_index = shard_base + (size_t)((pos / 64u) * wps + j) * 64u + pos % 64u;
+            next_pos += take;
+            if (got)
+            {
+                slot = queue[q_index];
+                const float4 orr = pb.ori_rng[slot];
+                const float4 dm = pb.dir_meta[slot];
+                bool trace = true;
+                if (TYPE == LUPIN_PATHTRACE_MIS)
+                {
+                    if (!(__float_as_uint(dm.w) & META_NEXT_EMISSION))   // reuse the BSDF-sampled hit (pathtracer.wgsl:751-755)
+                    {
+                        pb.hit[slot] = pb.next_hit[slot];
+                        pb.hit_tri[slot] = pb.next_tri[slot];
+                        trace = false;
+                    }
+                }
+                if (trace)
+                {
+                    o = mk3(orr.x, orr.y, orr.z);
+                    d = mk3(dm.x, dm.y, dm.z);
+                    rng = rng_in = __float_as_uint(orr.w);
+                    total_dst = 0.0f;
+                    alpha_k = 0;
+                    start_traversal();
+                    active = true;
+                }
+            }
+        }
+        if (!__any(active))
+        {
+            if (next_pos >= n_mine) break;
+            continue;   // unreachable in practice: an all-idle wave with work left refills above
+        }
+
+        // ---- phase 1: internal nodes of either level ----
+        while (active && !(cur & REF_LEAF))
+        {
+            const WideNode nd = nodes[cur];
+            float ld = slab_dst(co, cinv, nd.a.x, nd.a.y, nd.a.z, nd.a.w, nd.b.x, nd.b.y);
+            float rd = slab_dst(co, cinv, nd.b.z, nd.b.w, nd.c.x, nd.c.y, nd.c.z, nd.c.w);
+            bool left_first = ld <= rd;
+            bool push_l = ld < best.t, push_r = rd < best.t;
+            uint32_t near_ref = left_first ? nd.d.x : nd.d.y;
+            uint32_t far_ref = left_first ? nd.d.y : nd.d.x;
+            bool push_near = left_first ? push_l : push_r;
+            bool push_far = left_first ? push_r : push_l;
+            if (push_far) { lds_stack[sp * LP_BLOCK + tid] = far_ref; sp++; }
+            if (push_near) cur = near_ref; else pop();
+        }
+
+        // ---- phase 2: leaves, or the end of a traversal ----
+        if (active)
+        {
+            if (cur == REF_DONE)
+            {
+                // ray_skip_alpha_stochastically (bvh_custom.wgsl:154-180), one loop iteration per traversal
+                const bool hit = best.t != LP_F32_MAX;
+                bool again = false;
+                if (hit)
+                {
+                    total_dst += best.t;
+                    if (sc.instances[best.inst].flags & 1u)
+                    {
+                        Surface sf = resolve_surface(sc, best.inst, best.tri, best.u, best.v);
+                        float opacity = surface_opacity(sc, sf);
+                        if (opacity < 1.0f && rnd(rng) >= opacity)
+                        {
+                            o = add(o, scale(d, best.t));
+                            alpha_k++;
+                            again = alpha_k < 128u;   // MAX_OPACITY_BOUNCES (pathtracer.wgsl:1263)
+                        }
+                    }
+                }
+                if (again)
+                {
+                    start_traversal();
+                }
+                else
+                {
+                    pb.hit[slot] = make_float4(total_dst, best.u, best.v, __uint_as_float(hit ? best.inst : HIT_MISS));
+                    pb.hit_tri[slot] = best.tri;
+                    if (rng != rng_in) pb.ori_rng[slot].w = __uint_as_float(rng);
+                    active = false;
+                }
+            }
+            else if (blas_base == 0xFFFFFFFFu)
+            {
+                cur_inst = cur & ~REF_LEAF;
+                const InstanceDev in = sc.instances[cur_inst];
+                co = mk3(o.x * in.r0.x + o.y * in.r0.y + o.z * in.r0.z + 1.0f * in.r0.w,
+                         o.x * in.r1.x + o.y * in.r1.y + o.z * in.r1.z + 1.0f * in.r1.w,
+                         o.x * in.r2.x + o.y * in.r2.y + o.z * in.r2.z + 1.0f * in.r2.w);
+                cd = mk3(d.x * in.r0.x + d.y * in.r0.y + d.z * in.r0.z + 0.0f * in.r0.w,
+                         d.x * in.r1.x + d.y * in.r1.y + d.z * in.r1.z + 0.0f * in.r1.w,
+                         d.x * in.r2.x + d.y * in.r2.y + d.z * in.r2.z + 0.0f * in.r2.w);
+                cinv = mk3(1.0f / cd.x, 1.0f / cd.y, 1.0f / cd.z);
+                nodes = sc.blas;
+                blas_base = sp;
+                cur = in.blas_root;
+            }
+            else
+            {
+                uint32_t ti = cur & ~REF_LEAF;
+                for (;;)
+                {
+                    const TriVerts tv = sc.tris[ti];
+                    TriHit h = tri_dst(co, cd, xyz(tv.v0), xyz(tv.v1), xyz(tv.v2), eps);
+                    if (h.t < best.t) { best.t = h.t; best.u = h.u; best.v = h.v; best.tri = ti; best.inst = cur_inst; }
+                    if (__float_as_uint(tv.v0.w) & LEAF_END_BITS) break;
+                    ti++;
+                }
+                pop();
+            }
+        }
+    }
 }
 
 // clamp_radiance (pathtracer.wgsl:1774-1783)
@@ -680,6 +871,8 @@ struct LupinContext
     unsigned long long *stat_counters = nullptr;   // per shard: [2s] path bounces, [2s+1] paths
     bool timing = false;
     int store_rounding = 0;        // LUPIN_STORE_ROUND_TOWARD_ZERO
+    bool persistent_extend = false; // LUPIN_EXTEND=persistent selects the lane-refill kernel (measured slower)
+    uint32_t resident_blocks = 1024;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_extend, ev_shade, ev_total;
     std::vector<hipEvent_t> ev_pool;
     uint64_t extend_launches = 0;
@@ -762,7 +955,9 @@ static int ensure_path_buffers(LupinContext *ctx, uint64_t slots, uint32_t itera
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->pb.counts) hipFree(ctx->pb.counts);
         ctx->pb.counts = nullptr;
-        HIP_TRY(hipMalloc((void **)&ctx->pb.counts, (size_t)(iterations + 2) * LP_SHARDS * sizeof(uint32_t)));
+        // counts and heads live in one allocation so that a single memset clears both
+        HIP_TRY(hipMalloc((void **)&ctx->pb.counts, (size_t)(iterations + 2) * LP_SHARDS * sizeof(uint32_t) * 2));
+        ctx->pb.heads = ctx->pb.counts + (size_t)(iterations + 2) * LP_SHARDS;
         ctx->counts_capacity = iterations + 2;
     }
     return LUPIN_OK;
@@ -794,7 +989,11 @@ static void launch_iteration(LupinContext *ctx, const LupinScene *scene, const F
 {
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     if (ctx->timing) { e0 = get_event(ctx); e1 = get_event(ctx); e2 = get_event(ctx); hipEventRecord(e0, ctx->stream); }
-    hipLaunchKernelGGL(k_extend<TYPE>, dim3(blocks), dim3(LP_BLOCK), lds, ctx->stream, scene->dev, fp, ctx->pb, iter, ctx->stat_counters);
+    if (ctx->persistent_extend)
+        hipLaunchKernelGGL(k_extend_persistent<TYPE>, dim3(ctx->resident_blocks), dim3(LP_BLOCK), lds, ctx->stream,
+                           scene->dev, fp, ctx->pb, iter, ctx->stat_counters);
+    else
+        hipLaunchKernelGGL(k_extend<TYPE>, dim3(blocks), dim3(LP_BLOCK), lds, ctx->stream, scene->dev, fp, ctx->pb, iter, ctx->stat_counters);
     if (ctx->timing) hipEventRecord(e1, ctx->stream);
     hipLaunchKernelGGL(k_shade<TYPE>, dim3(blocks), dim3(LP_BLOCK), lds, ctx->stream, scene->dev, fp, ctx->pb, iter, ctx->stat_counters);
     if (ctx->timing)
@@ -831,6 +1030,16 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
     e = hipMalloc((void **)&ctx->stat_counters, 2 * LP_SHARDS * sizeof(unsigned long long));
     if (e != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return fail(LUPIN_ERR_HIP, "hipMalloc(stat counters)"); }
     hipMemsetAsync(ctx->stat_counters, 0, 2 * LP_SHARDS * sizeof(unsigned long long), ctx->stream);
+    const char *ext = getenv("LUPIN_EXTEND");
+    ctx->persistent_extend = (ext && strcmp(ext, "persistent") == 0);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0)
+    {
+        const char *bpc = getenv("LUPIN_EXTEND_BLOCKS_PER_CU");
+        int per_cu = bpc ? atoi(bpc) : 4;
+        ctx->resident_blocks = (uint32_t)prop.multiProcessorCount * (uint32_t)std::max(1, per_cu);
+        ctx->resident_blocks = std::max(64u, ctx->resident_blocks / 64u * 64u);   // whole waves-per-shard: multiple of LP_SHARDS waves
+    }
     *out_ctx = ctx;
     return LUPIN_OK;
 }
@@ -1372,7 +1581,7 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (ctx->timing) { t0 = get_event(ctx); t1 = get_event(ctx); hipEventRecord(t0, ctx->stream); }
 
-    HIP_TRY(hipMemsetAsync(ctx->pb.counts, 0, (size_t)(iterations + 2) * LP_SHARDS * sizeof(uint32_t), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->pb.counts, 0, (size_t)ctx->counts_capacity * LP_SHARDS * sizeof(uint32_t) * 2, ctx->stream));
     hipLaunchKernelGGL(k_begin, dim3(blocks), dim3(LP_BLOCK), 0, ctx->stream, fp, ctx->pb, n);
     for (uint32_t it = 0; it < iterations; it++)
     {

@@ -99,8 +99,6 @@ def gather_framebuffer(dist, ops, framebuffer, width, height, tile_size, rank, w
     Returns the number of payload bytes this rank contributed."""
     capacity = max(packed_pixels(width, height, tile_size, r, world) for r in range(world))
     mine = ops.pack(framebuffer, tile_size, rank, world, capacity)
-    if world == 1:
-        return capacity * 8
     torch = ops.torch
     gathered = torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device)
     dist.all_gather_into_tensor(gathered, mine)
