@@ -1,0 +1,45 @@
+"""The C++ host mirror (include/lupin.hpp, namespace lp:: / lpl::) and the example1.rs counterpart built on it."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "examples", "example1")
+
+
+@pytest.fixture(scope="module")
+def example1(built):
+    lib_dir = os.path.join(ROOT, "lupinpathtracer_amd")
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "example1.cpp"), "-L" + lib_dir, "-llupin_hip", "-L/opt/rocm/lib",
+           "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", EXE]
+    subprocess.check_call(cmd)
+    return EXE
+
+
+def test_example_compiles_and_refuses_to_run_without_a_device(example1):
+    from lupinpathtracer_amd import api
+    if api.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    p = subprocess.run([example1, "8", "1", "/tmp/_lupin_example.hdr"], capture_output=True, text=True)
+    assert p.returncode == 1
+    assert "no HIP device" in p.stderr and "no CPU fallback" in p.stderr
+
+
+@pytest.mark.gpu
+def test_example1_matches_python_host(gpu_ctx, example1, tmp_path):
+    """example1.rs's loop (5 spp x N frames, flip, extra flip, save) gives the same image through both host mirrors."""
+    from lupinpathtracer_amd import loader
+    from tests import util
+    out = str(tmp_path / "output.hdr")
+    subprocess.check_call([example1, "64", "6", out])
+    cpp = loader.read_hdr(out)
+    scene, cams = util.load_scene("cornellbox_builtin", gpu_ctx)
+    img = util.gpu_accumulate(gpu_ctx, scene, cams[0], 64, 64, frames=6, spp=5)
+    ref_path = str(tmp_path / "ref.hdr")
+    loader.save_texture(ref_path, img)
+    ref = loader.read_hdr(ref_path)
+    assert cpp.shape == ref.shape == (64, 64, 3)
+    assert np.array_equal(cpp, ref)
