@@ -99,6 +99,10 @@ struct SceneDev
     const AliasRange *env_alias_ranges;  // per environment
     const LupinAliasBin *alias_bins;     // pool
     uint32_t num_lights, num_envs, num_instances;
+    // small scenes: [tlas | blas | tris | instances] as one array of 16-byte words that kernels stage in LDS
+    const float4 *geo_blob;
+    uint32_t geo_blob_words;                       // 0 = scene too large, traverse from global memory
+    uint32_t geo_off_blas, geo_off_tris, geo_off_inst;   // offsets in 16-byte words (tlas starts at 0)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -221,6 +225,80 @@ LP_DEV TriHit tri_dst(f3 o, f3 d, f3 v0, f3 v1, f3 v2, float eps)
     return h;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Geometry access: the same traversal code runs over global memory or over a copy of the scene's
+// geometry staged in LDS (scenes up to LP_GEO_LDS_LIMIT bytes).  Divergent 64-byte node fetches cost
+// one L1 tag lookup per lane and 16 B; from LDS they are four ds_read_b128 per lane group.
+// ------------------------------------------------------------------------------------------------
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const v4f *lds_v4p;
+constexpr uint32_t LP_GEO_LDS_LIMIT = 24 * 1024;
+
+struct NodeRegs { float4 a, b, c; uint32_t left, right; };
+
+struct GeoGlobal
+{
+    const WideNode *tlas, *blas;
+    const TriVerts *tris;
+    const InstanceDev *instances;
+    LP_DEV NodeRegs node(bool in_blas, uint32_t i) const
+    {
+        const WideNode nd = (in_blas ? blas : tlas)[i];
+        NodeRegs r; r.a = nd.a; r.b = nd.b; r.c = nd.c; r.left = nd.d.x; r.right = nd.d.y;
+        return r;
+    }
+    LP_DEV TriVerts tri(uint32_t i) const { return tris[i]; }
+    LP_DEV InstanceDev inst(uint32_t i) const { return instances[i]; }
+};
+
+struct GeoLds
+{
+    lds_v4p base;
+    uint32_t off_blas, off_tris, off_inst;
+    static LP_DEV float4 f4(v4f v) { return make_float4(v.x, v.y, v.z, v.w); }
+    LP_DEV NodeRegs node(bool in_blas, uint32_t i) const
+    {
+        lds_v4p p = base + (in_blas ? off_blas : 0u) + i * 4u;
+        const v4f a = p[0], b = p[1], c = p[2], d = p[3];
+        NodeRegs r; r.a = f4(a); r.b = f4(b); r.c = f4(c); r.left = __float_as_uint(d.x); r.right = __float_as_uint(d.y);
+        return r;
+    }
+    LP_DEV TriVerts tri(uint32_t i) const
+    {
+        lds_v4p p = base + off_tris + i * 3u;
+        TriVerts t; t.v0 = f4(p[0]); t.v1 = f4(p[1]); t.v2 = f4(p[2]);
+        return t;
+    }
+    LP_DEV InstanceDev inst(uint32_t i) const
+    {
+        lds_v4p p = base + off_inst + i * 4u;
+        const v4f d = p[3];
+        InstanceDev in; in.r0 = f4(p[0]); in.r1 = f4(p[1]); in.r2 = f4(p[2]);
+        in.blas_root = __float_as_uint(d.x); in.mat_idx = __float_as_uint(d.y); in.mesh_idx = __float_as_uint(d.z); in.flags = __float_as_uint(d.w);
+        return in;
+    }
+};
+
+LP_DEV GeoGlobal geo_global(const SceneDev &sc)
+{
+    GeoGlobal g; g.tlas = sc.tlas; g.blas = sc.blas; g.tris = sc.tris; g.instances = sc.instances;
+    return g;
+}
+// Cooperative copy of the geometry blob into LDS at `words` (16-byte aligned); caller synchronises.
+LP_DEV GeoLds geo_stage_lds(const SceneDev &sc, uint32_t *lds_words)
+{
+    v4f *dst = (v4f *)lds_words;
+    for (uint32_t i = threadIdx.x; i < sc.geo_blob_words; i += LP_BLOCK)
+    {
+        const float4 t = sc.geo_blob[i];
+        dst[i] = (v4f){t.x, t.y, t.z, t.w};
+    }
+    GeoLds g; g.base = (lds_v4p)lds_words; g.off_blas = sc.geo_off_blas; g.off_tris = sc.geo_off_tris; g.off_inst = sc.geo_off_inst;
+    return g;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Traversal.  Per-lane stack lives in LDS, entry e of lane t at stack[e * LP_BLOCK + t]:
 // bank = t mod 32 for every depth, so pushes/pops never conflict inside a wave.
@@ -239,7 +317,8 @@ struct Closest
 
 // Descend one BLAS (bvh_custom.wgsl:195-288) from `root`, updating `best` on strictly closer hits.
 // Returns true if any triangle of this mesh replaced the best hit.
-LP_DEV bool blas_closest(const SceneDev &sc, uint32_t *stack, uint32_t sp_base, uint32_t root,
+template <typename Geo>
+LP_DEV bool blas_closest(const Geo &geo, uint32_t *stack, uint32_t sp_base, uint32_t root,
                          f3 o, f3 d, f3 inv_d, float eps, Closest &best)
 {
     const uint32_t tid = threadIdx.x;
@@ -253,7 +332,7 @@ LP_DEV bool blas_closest(const SceneDev &sc, uint32_t *stack, uint32_t sp_base, 
             uint32_t ti = cur & ~REF_LEAF;
             for (;;)
             {
-                const TriVerts tv = sc.tris[ti];
+                const TriVerts tv = geo.tri(ti);
                 TriHit h = tri_dst(o, d, xyz(tv.v0), xyz(tv.v1), xyz(tv.v2), eps);
                 if (h.t < best.t) { best.t = h.t; best.u = h.u; best.v = h.v; best.tri = ti; replaced = true; }
                 if (__float_as_uint(tv.v0.w) & LEAF_END_BITS) break;
@@ -265,13 +344,13 @@ LP_DEV bool blas_closest(const SceneDev &sc, uint32_t *stack, uint32_t sp_base, 
         }
         else
         {
-            const WideNode nd = sc.blas[cur];
+            const NodeRegs nd = geo.node(true, cur);
             float ld = slab_dst(o, inv_d, nd.a.x, nd.a.y, nd.a.z, nd.a.w, nd.b.x, nd.b.y);
             float rd = slab_dst(o, inv_d, nd.b.z, nd.b.w, nd.c.x, nd.c.y, nd.c.z, nd.c.w);
             bool left_first = ld <= rd;
             bool push_l = ld < best.t, push_r = rd < best.t;
-            uint32_t near_ref = left_first ? nd.d.x : nd.d.y;
-            uint32_t far_ref = left_first ? nd.d.y : nd.d.x;
+            uint32_t near_ref = left_first ? nd.left : nd.right;
+            uint32_t far_ref = left_first ? nd.right : nd.left;
             bool push_near = left_first ? push_l : push_r;
             bool push_far = left_first ? push_r : push_l;
             if (push_far) { stack[sp * LP_BLOCK + tid] = far_ref; sp++; }
@@ -295,7 +374,8 @@ LP_DEV bool blas_closest(const SceneDev &sc, uint32_t *stack, uint32_t sp_base, 
 // loop is organised "while-while": every lane first descends through internal nodes of either level
 // until it holds a leaf, then the wave handles leaves (instance entry / triangles) together.
 // Visiting order per lane is unchanged, so results are identical to the nested form.
-LP_DEV Closest scene_closest(const SceneDev &sc, uint32_t *stack, f3 o, f3 d, float eps)
+template <typename Geo>
+LP_DEV Closest scene_closest(const Geo &geo, const SceneDev &sc, uint32_t *stack, f3 o, f3 d, float eps)
 {
     const uint32_t tid = threadIdx.x;
     constexpr uint32_t REF_DONE = 0xFFFFFFFFu;   // not a valid leaf reference (leaf payloads are < 2^31 - 1)
@@ -305,7 +385,6 @@ LP_DEV Closest scene_closest(const SceneDev &sc, uint32_t *stack, f3 o, f3 d, fl
     const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
 
     f3 co = o, cd = d, cinv = inv_d;       // ray of the current level (world, or instance-local)
-    const WideNode *nodes = sc.tlas;
     uint32_t sp = 0;
     uint32_t blas_base = 0xFFFFFFFFu;      // stack height at instance entry; all-ones = at TLAS level
     uint32_t cur_inst = 0;
@@ -313,7 +392,7 @@ LP_DEV Closest scene_closest(const SceneDev &sc, uint32_t *stack, f3 o, f3 d, fl
 
     // pop the next reference; leaving an exhausted BLAS restores the world ray and keeps popping the TLAS part
     auto pop = [&]() {
-        if (sp == blas_base) { blas_base = 0xFFFFFFFFu; co = o; cd = d; cinv = inv_d; nodes = sc.tlas; }
+        if (sp == blas_base) { blas_base = 0xFFFFFFFFu; co = o; cd = d; cinv = inv_d; }
         if (sp == 0) { cur = REF_DONE; return; }
         sp--;
         cur = stack[sp * LP_BLOCK + tid];
@@ -324,13 +403,13 @@ LP_DEV Closest scene_closest(const SceneDev &sc, uint32_t *stack, f3 o, f3 d, fl
         // ---- phase 1: internal nodes of either level ----
         while (!(cur & REF_LEAF))
         {
-            const WideNode nd = nodes[cur];
+            const NodeRegs nd = geo.node(blas_base != 0xFFFFFFFFu, cur);
             float ld = slab_dst(co, cinv, nd.a.x, nd.a.y, nd.a.z, nd.a.w, nd.b.x, nd.b.y);
             float rd = slab_dst(co, cinv, nd.b.z, nd.b.w, nd.c.x, nd.c.y, nd.c.z, nd.c.w);
             bool left_first = ld <= rd;
             bool push_l = ld < best.t, push_r = rd < best.t;
-            uint32_t near_ref = left_first ? nd.d.x : nd.d.y;
-            uint32_t far_ref = left_first ? nd.d.y : nd.d.x;
+            uint32_t near_ref = left_first ? nd.left : nd.right;
+            uint32_t far_ref = left_first ? nd.right : nd.left;
             bool push_near = left_first ? push_l : push_r;
             bool push_far = left_first ? push_r : push_l;
             if (push_far) { stack[sp * LP_BLOCK + tid] = far_ref; sp++; }
@@ -343,7 +422,7 @@ LP_DEV Closest scene_closest(const SceneDev &sc, uint32_t *stack, f3 o, f3 d, fl
         {
             // TLAS leaf: enter the instance (bvh_custom.wgsl:28-37)
             cur_inst = cur & ~REF_LEAF;
-            const InstanceDev in = sc.instances[cur_inst];
+            const InstanceDev in = geo.inst(cur_inst);
             co = mk3(o.x * in.r0.x + o.y * in.r0.y + o.z * in.r0.z + 1.0f * in.r0.w,
                      o.x * in.r1.x + o.y * in.r1.y + o.z * in.r1.z + 1.0f * in.r1.w,
                      o.x * in.r2.x + o.y * in.r2.y + o.z * in.r2.z + 1.0f * in.r2.w);
@@ -351,7 +430,6 @@ LP_DEV Closest scene_closest(const SceneDev &sc, uint32_t *stack, f3 o, f3 d, fl
                      d.x * in.r1.x + d.y * in.r1.y + d.z * in.r1.z + 0.0f * in.r1.w,
                      d.x * in.r2.x + d.y * in.r2.y + d.z * in.r2.z + 0.0f * in.r2.w);
             cinv = mk3(1.0f / cd.x, 1.0f / cd.y, 1.0f / cd.z);
-            nodes = sc.blas;
             blas_base = sp;
             cur = in.blas_root;
         }
@@ -361,7 +439,7 @@ LP_DEV Closest scene_closest(const SceneDev &sc, uint32_t *stack, f3 o, f3 d, fl
             uint32_t ti = cur & ~REF_LEAF;
             for (;;)
             {
-                const TriVerts tv = sc.tris[ti];
+                const TriVerts tv = geo.tri(ti);
                 TriHit h = tri_dst(co, cd, xyz(tv.v0), xyz(tv.v1), xyz(tv.v2), eps);
                 if (h.t < best.t) { best.t = h.t; best.u = h.u; best.v = h.v; best.tri = ti; best.inst = cur_inst; }
                 if (__float_as_uint(tv.v0.w) & LEAF_END_BITS) break;
@@ -570,9 +648,10 @@ LP_DEV f3 normal_to_world(const InstanceDev &in, f3 n)
 }
 
 // compute_tri_geom_normal (pathtracer.wgsl:2561-2576)
-LP_DEV f3 geometric_normal(const SceneDev &sc, const InstanceDev &in, uint32_t gtri)
+template <typename Geo>
+LP_DEV f3 geometric_normal(const Geo &geo, const InstanceDev &in, uint32_t gtri)
 {
-    const TriVerts tv = sc.tris[gtri];
+    const TriVerts tv = geo.tri(gtri);
     f3 v0 = xyz(tv.v0), v1 = xyz(tv.v1), v2 = xyz(tv.v2);
     f3 local = normalize3(cross3(sub(v2, v0), sub(v1, v0)));
     return normal_to_world(in, local);
@@ -580,13 +659,14 @@ LP_DEV f3 geometric_normal(const SceneDev &sc, const InstanceDev &in, uint32_t g
 
 // compute_shading_normal (pathtracer.wgsl:1344-1384) incl. get_vert_normal (:1730-1755) and
 // compute_tangents_from_uv (:1699-1727)
-LP_DEV f3 shading_normal(const SceneDev &sc, const Surface &s)
+template <typename Geo>
+LP_DEV f3 shading_normal(const Geo &geo, const SceneDev &sc, const Surface &s)
 {
     f3 res;
     float w = 1.0f - s.u - s.v;
     if (s.mesh.normals_base == LUPIN_SENTINEL_IDX)
     {
-        res = geometric_normal(sc, s.in, s.gtri);
+        res = geometric_normal(geo, s.in, s.gtri);
     }
     else
     {
@@ -607,7 +687,7 @@ LP_DEV f3 shading_normal(const SceneDev &sc, const Surface &s)
             float2 uv2 = sc.texcoords[s.mesh.texcoords_base + s.i2];
             float tu = uv0.x * w + uv1.x * s.u + uv2.x * s.v;
             float tv_ = uv0.y * w + uv1.y * s.u + uv2.y * s.v;
-            const TriVerts tv = sc.tris[s.gtri];
+            const TriVerts tv = geo.tri(s.gtri);
             f3 p = sub(xyz(tv.v1), xyz(tv.v0));
             f3 q = sub(xyz(tv.v2), xyz(tv.v0));
             float sx = uv1.x - uv0.x, sy = uv2.x - uv0.x;
@@ -1306,7 +1386,8 @@ LP_DEV f3 lights_sample(const SceneDev &sc, f3 pos, uint32_t &rng)
     return env_texel_direction(sc, ei, texel);
 }
 
-LP_DEV float lights_pdf(const SceneDev &sc, uint32_t *stack, f3 pos, f3 incoming, float eps)
+template <typename Geo>
+LP_DEV float lights_pdf(const Geo &geo, const SceneDev &sc, uint32_t *stack, f3 pos, f3 incoming, float eps)
 {
     float pdf = 0.0f;
     // every emissive instance: march the ray through its BLAS (<= 100 crossings), no occlusion test
@@ -1314,7 +1395,7 @@ LP_DEV float lights_pdf(const SceneDev &sc, uint32_t *stack, f3 pos, f3 incoming
     for (uint32_t i = 0; i < sc.num_lights; i++)
     {
         const LupinLight light = sc.lights[i];
-        const InstanceDev in = sc.instances[light.instance_idx];
+        const InstanceDev in = geo.inst(light.instance_idx);
         float light_pdf = 0.0f;
         f3 next_pos = pos;
         for (uint32_t crossing = 0; crossing < 100u; crossing++)
@@ -1329,9 +1410,9 @@ LP_DEV float lights_pdf(const SceneDev &sc, uint32_t *stack, f3 pos, f3 incoming
             f3 linv = mk3(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
             Closest c;
             c.t = LP_F32_MAX; c.u = 0.0f; c.v = 0.0f; c.tri = 0u; c.inst = 0u;
-            blas_closest(sc, stack, 0u, in.blas_root, lo, ld, linv, eps, c);
+            blas_closest(geo, stack, 0u, in.blas_root, lo, ld, linv, eps, c);
             if (c.t == LP_F32_MAX) break;
-            f3 ln = geometric_normal(sc, in, c.tri);
+            f3 ln = geometric_normal(geo, in, c.tri);
             f3 light_pos = add(next_pos, scale(incoming, c.t));
             f3 dl = sub(light_pos, pos);
             float dist2 = dot3(dl, dl);

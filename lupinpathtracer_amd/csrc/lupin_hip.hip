@@ -193,11 +193,33 @@ __global__ void __launch_bounds__(LP_BLOCK) k_begin(FrameParams fp, PathBuffers 
 // instances whose opacity can differ from 1 (flag set at upload); for all others
 // opacity == 1 exactly, so `opacity < 1` is false and no random number is drawn -- identical to
 // the reference, which evaluates get_material_point for every hit.
-template <int TYPE>
-__global__ void __launch_bounds__(LP_BLOCK) k_extend(SceneDev sc, FrameParams fp, PathBuffers pb, uint32_t iter,
-                                                     unsigned long long *shard_stats)
+#ifndef LP_EXTEND_WAVES
+#define LP_EXTEND_WAVES 4
+#endif
+#ifndef LP_SHADE_WAVES
+#define LP_SHADE_WAVES 3
+#endif
+// dynamic LDS layout of the stage kernels: [traversal stacks: stack_entries * LP_BLOCK words][geometry blob, if staged]
+template <bool LDSGEO> struct GeoOf { typedef GeoGlobal type; };
+template <> struct GeoOf<true> { typedef GeoLds type; };
+template <bool LDSGEO>
+__device__ __forceinline__ typename GeoOf<LDSGEO>::type make_geo(const SceneDev &sc, uint32_t *lds, uint32_t stack_words);
+template <>
+__device__ __forceinline__ GeoGlobal make_geo<false>(const SceneDev &sc, uint32_t *, uint32_t) { return geo_global(sc); }
+template <>
+__device__ __forceinline__ GeoLds make_geo<true>(const SceneDev &sc, uint32_t *lds, uint32_t stack_words)
 {
-    extern __shared__ uint32_t lds_stack[];
+    GeoLds g = geo_stage_lds(sc, lds + stack_words);
+    __syncthreads();
+    return g;
+}
+
+template <int TYPE, bool LDSGEO>
+__global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launch_bounds__(LP_BLOCK) k_extend(SceneDev sc, FrameParams fp, PathBuffers pb, uint32_t iter,
+                                                     unsigned long long *shard_stats, uint32_t stack_words)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+    const auto geo = make_geo<LDSGEO>(sc, lds_stack, stack_words);
     const uint32_t shard = blockIdx.x % LP_SHARDS;
     const uint32_t count = pb.counts[iter * LP_SHARDS + shard];
     const uint32_t i = (blockIdx.x / LP_SHARDS) * LP_BLOCK + threadIdx.x;
@@ -227,7 +249,7 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend(SceneDev sc, FrameParams fp
     bool hit = false;
     for (uint32_t k = 0; k < 128u; k++)   // MAX_OPACITY_BOUNCES (pathtracer.wgsl:1263)
     {
-        c = scene_closest(sc, lds_stack, o, d, eps);
+        c = scene_closest(geo, sc, lds_stack, o, d, eps);
         hit = (c.t != LP_F32_MAX);
         if (!hit) break;
         total += c.t;
@@ -283,7 +305,7 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, Fra
     float total_dst = 0.0f;
     f3 o = splat(0.0f), d = splat(0.0f), inv_d = splat(0.0f);
     f3 co = o, cd = d, cinv = inv_d;
-    const WideNode *nodes = sc.tlas;
+    const GeoGlobal geo = geo_global(sc);
     uint32_t sp = 0, blas_base = 0xFFFFFFFFu, cur_inst = 0, cur = REF_DONE;
     Closest best;
     best.t = LP_F32_MAX; best.u = 0.0f; best.v = 0.0f; best.tri = 0u; best.inst = HIT_MISS;
@@ -291,13 +313,12 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, Fra
     auto start_traversal = [&]() {
         inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         co = o; cd = d; cinv = inv_d;
-        nodes = sc.tlas;
         sp = 0; blas_base = 0xFFFFFFFFu;
         cur = sc.num_instances ? sc.tlas_root : REF_DONE;
         best.t = LP_F32_MAX; best.u = 0.0f; best.v = 0.0f; best.tri = 0u; best.inst = HIT_MISS;
     };
     auto pop = [&]() {
-        if (sp == blas_base) { blas_base = 0xFFFFFFFFu; co = o; cd = d; cinv = inv_d; nodes = sc.tlas; }
+        if (sp == blas_base) { blas_base = 0xFFFFFFFFu; co = o; cd = d; cinv = inv_d; }
         if (sp == 0) { cur = REF_DONE; return; }
         sp--;
         cur = lds_stack[sp * LP_BLOCK + tid];
@@ -352,13 +373,13 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, Fra
         // ---- phase 1: internal nodes of either level ----
         while (active && !(cur & REF_LEAF))
         {
-            const WideNode nd = nodes[cur];
+            const NodeRegs nd = geo.node(blas_base != 0xFFFFFFFFu, cur);
             float ld = slab_dst(co, cinv, nd.a.x, nd.a.y, nd.a.z, nd.a.w, nd.b.x, nd.b.y);
             float rd = slab_dst(co, cinv, nd.b.z, nd.b.w, nd.c.x, nd.c.y, nd.c.z, nd.c.w);
             bool left_first = ld <= rd;
             bool push_l = ld < best.t, push_r = rd < best.t;
-            uint32_t near_ref = left_first ? nd.d.x : nd.d.y;
-            uint32_t far_ref = left_first ? nd.d.y : nd.d.x;
+            uint32_t near_ref = left_first ? nd.left : nd.right;
+            uint32_t far_ref = left_first ? nd.right : nd.left;
             bool push_near = left_first ? push_l : push_r;
             bool push_far = left_first ? push_r : push_l;
             if (push_far) { lds_stack[sp * LP_BLOCK + tid] = far_ref; sp++; }
@@ -411,7 +432,6 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, Fra
                          d.x * in.r1.x + d.y * in.r1.y + d.z * in.r1.z + 0.0f * in.r1.w,
                          d.x * in.r2.x + d.y * in.r2.y + d.z * in.r2.z + 0.0f * in.r2.w);
                 cinv = mk3(1.0f / cd.x, 1.0f / cd.y, 1.0f / cd.z);
-                nodes = sc.blas;
                 blas_base = sp;
                 cur = in.blas_root;
             }
@@ -455,8 +475,8 @@ struct PathRegs
 // path continues with (ori, dir) set for the next bounce, false on `break`.
 // TYPE 0: pathtrace_standard (:588-733)   1: pathtrace_mis (:737-933)
 //      2: pathtrace_naive (:942-1059)     3: pathtrace_direct (:1062-1245)
-template <int TYPE>
-__device__ bool integrate_vertex(const SceneDev &sc, uint32_t *stack, const FrameParams &fp, PathRegs &p,
+template <int TYPE, typename Geo>
+__device__ bool integrate_vertex(const Geo &geo, const SceneDev &sc, uint32_t *stack, const FrameParams &fp, PathRegs &p,
                                  float4 hitrec, uint32_t hit_tri, PathBuffers &pb, uint32_t slot)
 {
     const float eps = fp.pc.ray_epsilon;
@@ -491,7 +511,7 @@ __device__ bool integrate_vertex(const SceneDev &sc, uint32_t *stack, const Fram
         hit_pos = add(p.ori, scale(p.dir, hit_dst));
         const Surface s = resolve_surface(sc, hit_inst, hit_tri, hitrec.y, hitrec.z);
         const MatPoint mp = material_point(sc, s);
-        const f3 normal = shading_normal(sc, s);
+        const f3 normal = shading_normal(geo, sc, s);
 
         if (TYPE == LUPIN_PATHTRACE_STANDARD || TYPE == LUPIN_PATHTRACE_NAIVE || p.next_emission)
             p.radiance = add(p.radiance, mul(p.weight, mp.emission));
@@ -503,11 +523,11 @@ __device__ bool integrate_vertex(const SceneDev &sc, uint32_t *stack, const Fram
             if (!delta)
             {
                 f3 li = lights_sample(sc, hit_pos, p.rng);
-                float pdf = lights_pdf(sc, stack, hit_pos, li, eps);
+                float pdf = lights_pdf(geo, sc, stack, hit_pos, li, eps);
                 f3 bsdfcos = bsdf_eval(mp, normal, outgoing, li);
                 if (none_zero3(bsdfcos) && pdf > 0.0f)
                 {
-                    Closest lc = scene_closest(sc, stack, hit_pos, li, eps);
+                    Closest lc = scene_closest(geo, sc, stack, hit_pos, li, eps);
                     f3 emission;
                     if (lc.t != LP_F32_MAX)
                         emission = material_point(sc, resolve_surface(sc, lc.inst, lc.tri, lc.u, lc.v)).emission;
@@ -533,7 +553,7 @@ __device__ bool integrate_vertex(const SceneDev &sc, uint32_t *stack, const Fram
                 }
                 else incoming = lights_sample(sc, hit_pos, p.rng);
                 if (is_zero3(incoming)) return false;
-                float prob = 0.5f * bsdf_pdf(mp, normal, outgoing, incoming) + 0.5f * lights_pdf(sc, stack, hit_pos, incoming, eps);
+                float prob = 0.5f * bsdf_pdf(mp, normal, outgoing, incoming) + 0.5f * lights_pdf(geo, sc, stack, hit_pos, incoming, eps);
                 p.weight = mul(p.weight, divs(bsdf_eval(mp, normal, outgoing, incoming), prob));
             }
             else if (TYPE == LUPIN_PATHTRACE_NAIVE)
@@ -561,7 +581,7 @@ __device__ bool integrate_vertex(const SceneDev &sc, uint32_t *stack, const Fram
                     if (!light_turn) incoming = mi;
 
                     f3 bsdfcos = bsdf_eval(mp, normal, outgoing, mi);
-                    float light_pdf = lights_pdf(sc, stack, hit_pos, mi, eps);
+                    float light_pdf = lights_pdf(geo, sc, stack, hit_pos, mi, eps);
                     float b_pdf = bsdf_pdf(mp, normal, outgoing, mi);
                     float mis_w;
                     if (light_turn) mis_w = (light_pdf * light_pdf) / (light_pdf * light_pdf + b_pdf * b_pdf) / light_pdf;
@@ -569,7 +589,7 @@ __device__ bool integrate_vertex(const SceneDev &sc, uint32_t *stack, const Fram
 
                     if (none_zero3(bsdfcos) && mis_w != 0.0f)
                     {
-                        Closest mc = scene_closest(sc, stack, hit_pos, mi, eps);
+                        Closest mc = scene_closest(geo, sc, stack, hit_pos, mi, eps);
                         const bool mhit = mc.t != LP_F32_MAX;
                         if (!light_turn)
                         {
@@ -631,7 +651,7 @@ __device__ bool integrate_vertex(const SceneDev &sc, uint32_t *stack, const Fram
             else incoming = lights_sample(sc, hit_pos, p.rng);
             if (TYPE == LUPIN_PATHTRACE_MIS) p.next_emission = true;
             if (is_zero3(incoming)) return false;
-            float prob = 0.5f * phase_pdf(p.medium, outgoing, incoming) + 0.5f * lights_pdf(sc, stack, hit_pos, incoming, eps);
+            float prob = 0.5f * phase_pdf(p.medium, outgoing, incoming) + 0.5f * lights_pdf(geo, sc, stack, hit_pos, incoming, eps);
             p.weight = mul(p.weight, divs(phase_eval(p.medium, outgoing, incoming), prob));
         }
     }
@@ -650,11 +670,12 @@ __device__ bool integrate_vertex(const SceneDev &sc, uint32_t *stack, const Fram
     return true;
 }
 
-template <int TYPE>
-__global__ void __launch_bounds__(LP_BLOCK) k_shade(SceneDev sc, FrameParams fp, PathBuffers pb, uint32_t iter,
-                                                    unsigned long long *shard_stats)
+template <int TYPE, bool LDSGEO>
+__global__ void __attribute__((amdgpu_waves_per_eu(TYPE == 0 || TYPE == 2 ? LP_SHADE_WAVES : 1, 8))) __launch_bounds__(LP_BLOCK) k_shade(SceneDev sc, FrameParams fp, PathBuffers pb, uint32_t iter,
+                                                    unsigned long long *shard_stats, uint32_t stack_words)
 {
-    extern __shared__ uint32_t lds_stack[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+    const auto geo = make_geo<LDSGEO>(sc, lds_stack, stack_words);
     const uint32_t shard = blockIdx.x % LP_SHARDS;
     const uint32_t count = pb.counts[iter * LP_SHARDS + shard];
     const uint32_t i = (blockIdx.x / LP_SHARDS) * LP_BLOCK + threadIdx.x;
@@ -689,7 +710,7 @@ __global__ void __launch_bounds__(LP_BLOCK) k_shade(SceneDev sc, FrameParams fp,
         }
         else { p.medium.density = splat(0.0f); p.medium.scattering = splat(0.0f); p.medium.anisotropy = 0.0f; }
 
-        bool cont = integrate_vertex<TYPE>(sc, lds_stack, fp, p, pb.hit[slot], pb.hit_tri[slot], pb, slot);
+        bool cont = integrate_vertex<TYPE>(geo, sc, lds_stack, fp, p, pb.hit[slot], pb.hit_tri[slot], pb, slot);
         if (cont)
         {
             p.bounce++;
@@ -788,7 +809,7 @@ __global__ void __launch_bounds__(LP_BLOCK) k_trace(SceneDev sc, uint32_t n, con
     if (i >= n) return;
     f3 o = mk3(ori[i * 3 + 0], ori[i * 3 + 1], ori[i * 3 + 2]);
     f3 d = mk3(dir[i * 3 + 0], dir[i * 3 + 1], dir[i * 3 + 2]);
-    Closest c = scene_closest(sc, lds_stack, o, d, eps);
+    Closest c = scene_closest(geo_global(sc), sc, lds_stack, o, d, eps);
     bool hit = c.t != LP_F32_MAX;
     out_hit[i] = hit ? 1u : 0u;
     out_dst[i] = hit ? c.t : 0.0f;
@@ -871,6 +892,7 @@ struct LupinContext
     unsigned long long *stat_counters = nullptr;   // per shard: [2s] path bounces, [2s+1] paths
     bool timing = false;
     int store_rounding = 0;        // LUPIN_STORE_ROUND_TOWARD_ZERO
+    bool lds_geometry = true;       // LUPIN_LDS_GEOMETRY=0 keeps small scenes in global memory (A/B runs)
     bool persistent_extend = false; // LUPIN_EXTEND=persistent selects the lane-refill kernel (measured slower)
     uint32_t resident_blocks = 1024;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_extend, ev_shade, ev_total;
@@ -984,18 +1006,18 @@ static uint32_t blas_depth(const LupinBvhNode *nodes, uint32_t count)
     return best;
 }
 
-template <int TYPE>
-static void launch_iteration(LupinContext *ctx, const LupinScene *scene, const FrameParams &fp, uint32_t blocks, size_t lds, uint32_t iter)
+template <int TYPE, bool LDSGEO>
+static void launch_iteration_t(LupinContext *ctx, const LupinScene *scene, const FrameParams &fp, uint32_t blocks, size_t lds, uint32_t stack_words, uint32_t iter)
 {
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     if (ctx->timing) { e0 = get_event(ctx); e1 = get_event(ctx); e2 = get_event(ctx); hipEventRecord(e0, ctx->stream); }
-    if (ctx->persistent_extend)
+    if (ctx->persistent_extend && !LDSGEO)
         hipLaunchKernelGGL(k_extend_persistent<TYPE>, dim3(ctx->resident_blocks), dim3(LP_BLOCK), lds, ctx->stream,
                            scene->dev, fp, ctx->pb, iter, ctx->stat_counters);
     else
-        hipLaunchKernelGGL(k_extend<TYPE>, dim3(blocks), dim3(LP_BLOCK), lds, ctx->stream, scene->dev, fp, ctx->pb, iter, ctx->stat_counters);
+        hipLaunchKernelGGL((k_extend<TYPE, LDSGEO>), dim3(blocks), dim3(LP_BLOCK), lds, ctx->stream, scene->dev, fp, ctx->pb, iter, ctx->stat_counters, stack_words);
     if (ctx->timing) hipEventRecord(e1, ctx->stream);
-    hipLaunchKernelGGL(k_shade<TYPE>, dim3(blocks), dim3(LP_BLOCK), lds, ctx->stream, scene->dev, fp, ctx->pb, iter, ctx->stat_counters);
+    hipLaunchKernelGGL((k_shade<TYPE, LDSGEO>), dim3(blocks), dim3(LP_BLOCK), lds, ctx->stream, scene->dev, fp, ctx->pb, iter, ctx->stat_counters, stack_words);
     if (ctx->timing)
     {
         hipEventRecord(e2, ctx->stream);
@@ -1003,6 +1025,13 @@ static void launch_iteration(LupinContext *ctx, const LupinScene *scene, const F
         ctx->ev_shade.push_back({e1, e2});
     }
     ctx->extend_launches++;
+}
+
+template <int TYPE>
+static void launch_iteration(LupinContext *ctx, const LupinScene *scene, const FrameParams &fp, uint32_t blocks, size_t lds, uint32_t stack_words, uint32_t iter)
+{
+    if (scene->dev.geo_blob_words && ctx->lds_geometry) launch_iteration_t<TYPE, true>(ctx, scene, fp, blocks, lds, stack_words, iter);
+    else launch_iteration_t<TYPE, false>(ctx, scene, fp, blocks, lds, stack_words, iter);
 }
 
 extern "C" {
@@ -1032,6 +1061,8 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
     hipMemsetAsync(ctx->stat_counters, 0, 2 * LP_SHARDS * sizeof(unsigned long long), ctx->stream);
     const char *ext = getenv("LUPIN_EXTEND");
     ctx->persistent_extend = (ext && strcmp(ext, "persistent") == 0);
+    const char *lg = getenv("LUPIN_LDS_GEOMETRY");
+    ctx->lds_geometry = !(lg && strcmp(lg, "0") == 0);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0)
     {
@@ -1362,6 +1393,27 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
         if (nb) alias_bins.insert(alias_bins.end(), s.env_alias_tables[i].bins, s.env_alias_tables[i].bins + nb);
     }
 
+    // small scenes: one blob [tlas | blas | tris | instances] in 16-byte words for LDS staging
+    std::vector<float4> geo_blob;
+    uint32_t off_blas = 0, off_tris = 0, off_inst = 0;
+    {
+        const size_t bytes = tlas.size() * 64 + blas.size() * 64 + tris.size() * 48 + instances.size() * 64;
+        if (bytes > 0 && bytes <= LP_GEO_LDS_LIMIT)
+        {
+            auto append = [&](const void *p, size_t nbytes) {
+                const float4 *f = reinterpret_cast<const float4 *>(p);
+                geo_blob.insert(geo_blob.end(), f, f + nbytes / 16);
+            };
+            append(tlas.data(), tlas.size() * 64);
+            off_blas = (uint32_t)geo_blob.size();
+            append(blas.data(), blas.size() * 64);
+            off_tris = (uint32_t)geo_blob.size();
+            append(tris.data(), tris.size() * 48);
+            off_inst = (uint32_t)geo_blob.size();
+            append(instances.data(), instances.size() * 64);
+        }
+    }
+
     SceneDev &dv = sc->dev;
     int rc = LUPIN_OK;
     std::vector<LupinMaterial> materials(s.materials, s.materials + s.num_materials);
@@ -1374,7 +1426,7 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
         (rc = upload(sc, textures, &dv.textures)) || (rc = upload(sc, texels, &dv.texels)) ||
         (rc = upload(sc, envs, &dv.environments)) || (rc = upload(sc, lights, &dv.lights)) ||
         (rc = upload(sc, alias_ranges, &dv.alias_ranges)) || (rc = upload(sc, env_alias_ranges, &dv.env_alias_ranges)) ||
-        (rc = upload(sc, alias_bins, &dv.alias_bins)))
+        (rc = upload(sc, alias_bins, &dv.alias_bins)) || (rc = upload(sc, geo_blob, &dv.geo_blob)))
     {
         lupin_hip_scene_destroy(sc);
         return rc;
@@ -1383,6 +1435,8 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
     dv.num_lights = s.num_lights;
     dv.num_envs = s.num_environments;
     dv.num_instances = s.num_instances;
+    dv.geo_blob_words = (uint32_t)geo_blob.size();
+    dv.geo_off_blas = off_blas; dv.geo_off_tris = off_tris; dv.geo_off_inst = off_inst;
     hipError_t e = hipStreamSynchronize(ctx->stream);   // host vectors go out of scope
     if (e != hipSuccess) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_HIP, hipGetErrorString(e)); }
     *out_scene = sc;
@@ -1575,7 +1629,9 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
     const uint32_t blocks_per_shard = (blocks_needed + LP_SHARDS - 1) / LP_SHARDS;
     const uint32_t blocks = blocks_per_shard * LP_SHARDS;
     ctx->pb.shard_cap = blocks_per_shard * LP_BLOCK;
-    const size_t lds = (size_t)scene->stack_entries * LP_BLOCK * sizeof(uint32_t);
+    const uint32_t stack_words = scene->stack_entries * LP_BLOCK;
+    const bool lds_geo = scene->dev.geo_blob_words && ctx->lds_geometry;
+    const size_t lds = (size_t)stack_words * sizeof(uint32_t) + (lds_geo ? (size_t)scene->dev.geo_blob_words * 16 : 0);
     if (lds > 160 * 1024) return fail(LUPIN_ERR_INVALID_ARGUMENT, "BVH too deep for the LDS traversal stack");
 
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -1587,10 +1643,10 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
     {
         switch (pathtrace_type)
         {
-        case LUPIN_PATHTRACE_STANDARD: launch_iteration<LUPIN_PATHTRACE_STANDARD>(ctx, scene, fp, blocks, lds, it); break;
-        case LUPIN_PATHTRACE_MIS: launch_iteration<LUPIN_PATHTRACE_MIS>(ctx, scene, fp, blocks, lds, it); break;
-        case LUPIN_PATHTRACE_NAIVE: launch_iteration<LUPIN_PATHTRACE_NAIVE>(ctx, scene, fp, blocks, lds, it); break;
-        default: launch_iteration<LUPIN_PATHTRACE_DIRECT>(ctx, scene, fp, blocks, lds, it); break;
+        case LUPIN_PATHTRACE_STANDARD: launch_iteration<LUPIN_PATHTRACE_STANDARD>(ctx, scene, fp, blocks, lds, stack_words, it); break;
+        case LUPIN_PATHTRACE_MIS: launch_iteration<LUPIN_PATHTRACE_MIS>(ctx, scene, fp, blocks, lds, stack_words, it); break;
+        case LUPIN_PATHTRACE_NAIVE: launch_iteration<LUPIN_PATHTRACE_NAIVE>(ctx, scene, fp, blocks, lds, stack_words, it); break;
+        default: launch_iteration<LUPIN_PATHTRACE_DIRECT>(ctx, scene, fp, blocks, lds, stack_words, it); break;
         }
     }
     hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(LP_BLOCK), 0, ctx->stream, fp, ctx->pb, n,
