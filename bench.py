@@ -153,8 +153,17 @@ def main():
             bytes_per_launch = per_unit * kst["path_bounces"] / launches
             avg_launch_s = ms * 1e-3 / launches
             achieved = bytes_per_launch / avg_launch_s / 1e9
+            # HBM bytes per launch from the PMC passes of the same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+            # runs, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); summary committed under profiles/
+            traffic = None
+            pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            if os.path.exists(pmc_path):
+                with open(pmc_path) as f:
+                    pmc = json.load(f)
+                if name in pmc.get("hbm_bytes_per_unit", {}):
+                    traffic = pmc["hbm_bytes_per_unit"][name] * kst["path_bounces"] / launches
             roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                         "bytes_per_unit": per_unit, "units_per_launch": kst["path_bounces"] / launches,
                         "avg_launch_us": avg_launch_s * 1e6,
                         "note": "algorithmic bytes in the reference's layout; scene is cache-resident, HBM traffic itself is far lower"}

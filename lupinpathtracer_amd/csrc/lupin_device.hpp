@@ -15,6 +15,14 @@
 #include "../../include/lupin_detmath.h"
 
 #define LP_DEV __device__ __forceinline__
+// Bulky helpers (materials, lights, textures).  Fully inlined k_shade is 142 KB of code; turning these into real
+// functions (-DLP_OUTLINE_HELPERS) shrinks it to 18 KB + callees but the AMDGPU call ABI spills through scratch and
+// the bench drops 5.25 -> 1.69 Gsamples/s, so inlining stays the default.
+#ifdef LP_OUTLINE_HELPERS
+#define LP_FN __device__ __attribute__((noinline))
+#else
+#define LP_FN __device__ __forceinline__
+#endif
 #define LP_BLOCK 256
 
 namespace lpd {
@@ -478,7 +486,7 @@ LP_DEV float4 lerp_texels(float4 p, float4 q, float f)
     return make_float4(p.x * g + q.x * f, p.y * g + q.y * f, p.z * g + q.z * f, p.w * g + q.w * f);
 }
 
-LP_DEV float4 sample_texture(const SceneDev &sc, uint32_t tex_idx, float u, float v)
+LP_FN float4 sample_texture(const SceneDev &sc, uint32_t tex_idx, float u, float v)
 {
     const TextureDev t = sc.textures[tex_idx];
     int w = (int)t.width, h = (int)t.height;
@@ -561,7 +569,7 @@ LP_DEV float4 vertex_color(const SceneDev &sc, const Surface &s)
 
 // Opacity alone (the only field ray_skip_alpha_stochastically needs, bvh_custom.wgsl:168-169):
 // color_sample.a * mat.color.a * vert_color.a of get_material_point (pathtracer.wgsl:1314).
-LP_DEV float surface_opacity(const SceneDev &sc, const Surface &s)
+LP_FN float surface_opacity(const SceneDev &sc, const Surface &s)
 {
     const LupinMaterial *m = &sc.materials[s.in.mat_idx];
     float tex_a = 1.0f;
@@ -576,7 +584,7 @@ LP_DEV float surface_opacity(const SceneDev &sc, const Surface &s)
 }
 
 // get_material_point (pathtracer.wgsl:1265-1342)
-LP_DEV MatPoint material_point(const SceneDev &sc, const Surface &s)
+LP_FN MatPoint material_point(const SceneDev &sc, const Surface &s)
 {
     const LupinMaterial m = sc.materials[s.in.mat_idx];
     MatPoint r;
@@ -660,7 +668,7 @@ LP_DEV f3 geometric_normal(const Geo &geo, const InstanceDev &in, uint32_t gtri)
 // compute_shading_normal (pathtracer.wgsl:1344-1384) incl. get_vert_normal (:1730-1755) and
 // compute_tangents_from_uv (:1699-1727)
 template <typename Geo>
-LP_DEV f3 shading_normal(const Geo &geo, const SceneDev &sc, const Surface &s)
+LP_FN f3 shading_normal(const Geo &geo, const SceneDev &sc, const Surface &s)
 {
     f3 res;
     float w = 1.0f - s.u - s.v;
@@ -730,7 +738,7 @@ LP_DEV void dir_to_env_uv(const LupinEnvironment &env, f3 dir, float &u, float &
     if (u > 1.0f) u -= 1.0f;
 }
 
-LP_DEV f3 environment_radiance(const SceneDev &sc, f3 dir)
+LP_FN f3 environment_radiance(const SceneDev &sc, f3 dir)
 {
     f3 total = splat(0.0f);
     for (uint32_t i = 0; i < sc.num_envs; i++)
@@ -749,7 +757,7 @@ LP_DEV f3 environment_radiance(const SceneDev &sc, f3 dir)
     return total;
 }
 
-LP_DEV f3 env_texel_direction(const SceneDev &sc, uint32_t env_i, uint32_t texel)
+LP_FN f3 env_texel_direction(const SceneDev &sc, uint32_t env_i, uint32_t texel)
 {
     const LupinEnvironment &env = sc.environments[env_i];
     const TextureDev t = sc.textures[env.emission_tex_idx];
@@ -939,7 +947,7 @@ LP_DEV f3 gltf_reflectivity(const MatPoint &m)
     return mk3(base * g + m.color.x * m.metallic, base * g + m.color.y * m.metallic, base * g + m.color.z * m.metallic);
 }
 
-LP_DEV f3 bsdf_sample(const MatPoint &m, f3 normal, f3 outgoing, float rnl, float r0, float r1)
+LP_FN f3 bsdf_sample(const MatPoint &m, f3 normal, f3 outgoing, float rnl, float r0, float r1)
 {
     if (m.roughness == 0.0f) return splat(0.0f);
     switch (m.type)
@@ -1008,7 +1016,7 @@ LP_DEV f3 bsdf_sample(const MatPoint &m, f3 normal, f3 outgoing, float rnl, floa
     }
 }
 
-LP_DEV f3 bsdf_eval(const MatPoint &m, f3 normal, f3 outgoing, f3 incoming)
+LP_FN f3 bsdf_eval(const MatPoint &m, f3 normal, f3 outgoing, f3 incoming)
 {
     if (m.roughness == 0.0f) return splat(0.0f);
     float ndi = dot3(normal, incoming), ndo = dot3(normal, outgoing);
@@ -1115,7 +1123,7 @@ LP_DEV f3 bsdf_eval(const MatPoint &m, f3 normal, f3 outgoing, f3 incoming)
     }
 }
 
-LP_DEV float bsdf_pdf(const MatPoint &m, f3 normal, f3 outgoing, f3 incoming)
+LP_FN float bsdf_pdf(const MatPoint &m, f3 normal, f3 outgoing, f3 incoming)
 {
     if (m.roughness == 0.0f) return 0.0f;
     float ndi = dot3(normal, incoming), ndo = dot3(normal, outgoing);
@@ -1185,7 +1193,7 @@ LP_DEV float bsdf_pdf(const MatPoint &m, f3 normal, f3 outgoing, f3 incoming)
 // Delta lobes (pathtracer.wgsl:2231-2404)
 // ------------------------------------------------------------------------------------------------
 
-LP_DEV f3 delta_sample(const MatPoint &m, f3 normal, f3 outgoing, float rnl)
+LP_FN f3 delta_sample(const MatPoint &m, f3 normal, f3 outgoing, float rnl)
 {
     if (m.roughness != 0.0f) return splat(0.0f);
     switch (m.type)
@@ -1213,7 +1221,7 @@ LP_DEV f3 delta_sample(const MatPoint &m, f3 normal, f3 outgoing, float rnl)
     }
 }
 
-LP_DEV f3 delta_eval(const MatPoint &m, f3 normal, f3 outgoing, f3 incoming)
+LP_FN f3 delta_eval(const MatPoint &m, f3 normal, f3 outgoing, f3 incoming)
 {
     if (m.roughness != 0.0f) return splat(0.0f);
     float side = dot3(normal, incoming) * dot3(normal, outgoing);
@@ -1246,7 +1254,7 @@ LP_DEV f3 delta_eval(const MatPoint &m, f3 normal, f3 outgoing, f3 incoming)
     }
 }
 
-LP_DEV float delta_pdf(const MatPoint &m, f3 normal, f3 outgoing, f3 incoming)
+LP_FN float delta_pdf(const MatPoint &m, f3 normal, f3 outgoing, f3 incoming)
 {
     if (m.roughness != 0.0f) return 0.0f;
     float side = dot3(normal, incoming) * dot3(normal, outgoing);
@@ -1347,7 +1355,7 @@ LP_DEV uint32_t alias_pick(const SceneDev &sc, AliasRange rg, uint32_t &rng)
     return (rnd(rng) >= bin.alias_threshold) ? bin.alias : slot;
 }
 
-LP_DEV f3 lights_sample(const SceneDev &sc, f3 pos, uint32_t &rng)
+LP_FN f3 lights_sample(const SceneDev &sc, f3 pos, uint32_t &rng)
 {
     uint32_t nl = sc.num_lights, ne = sc.num_envs;
     if (nl + ne == 0) return splat(0.0f);
@@ -1387,7 +1395,7 @@ LP_DEV f3 lights_sample(const SceneDev &sc, f3 pos, uint32_t &rng)
 }
 
 template <typename Geo>
-LP_DEV float lights_pdf(const Geo &geo, const SceneDev &sc, uint32_t *stack, f3 pos, f3 incoming, float eps)
+LP_FN float lights_pdf(const Geo &geo, const SceneDev &sc, uint32_t *stack, f3 pos, f3 incoming, float eps)
 {
     float pdf = 0.0f;
     // every emissive instance: march the ray through its BLAS (<= 100 crossings), no occlusion test

@@ -83,7 +83,7 @@ struct FrameParams
 // Camera (compute_camera_ray, pathtracer.wgsl:505-542) -- draws 2 (jitter) + 2 (lens) numbers
 // ------------------------------------------------------------------------------------------------
 
-__device__ void camera_ray(const FrameParams &fp, uint32_t gx, uint32_t gy, uint32_t &rng, f3 &ori, f3 &dir)
+LP_FN void camera_ray(const FrameParams &fp, uint32_t gx, uint32_t gy, uint32_t &rng, f3 &ori, f3 &dir)
 {
     const LupinPushConstants &pc = fp.pc;
     float j0 = rnd(rng), j1 = rnd(rng);
@@ -214,6 +214,32 @@ __device__ __forceinline__ GeoLds make_geo<true>(const SceneDev &sc, uint32_t *l
     return g;
 }
 
+// One closest-hit query of the integrator loop, with stochastic alpha skipping (bvh_custom.wgsl:154-180).
+// Returns the hit record (dst accumulated over skipped surfaces | u | v | instance or HIT_MISS) and the triangle.
+template <typename Geo>
+__device__ __forceinline__ void trace_alpha(const Geo &geo, const SceneDev &sc, uint32_t *stack, f3 o, f3 d, uint32_t &rng, float eps,
+                                            float4 &hitrec, uint32_t &hit_tri)
+{
+    float total = 0.0f;
+    Closest c;
+    c.t = LP_F32_MAX; c.u = 0.0f; c.v = 0.0f; c.tri = 0u; c.inst = HIT_MISS;
+    bool hit = false;
+    for (uint32_t k = 0; k < 128u; k++)   // MAX_OPACITY_BOUNCES (pathtracer.wgsl:1263)
+    {
+        c = scene_closest(geo, sc, stack, o, d, eps);
+        hit = (c.t != LP_F32_MAX);
+        if (!hit) break;
+        total += c.t;
+        if (!(sc.instances[c.inst].flags & 1u)) break;
+        Surface s = resolve_surface(sc, c.inst, c.tri, c.u, c.v);
+        float opacity = surface_opacity(sc, s);
+        if (opacity < 1.0f && rnd(rng) >= opacity) o = add(o, scale(d, c.t));
+        else break;
+    }
+    hitrec = make_float4(total, c.u, c.v, __uint_as_float(hit ? c.inst : HIT_MISS));
+    hit_tri = c.tri;
+}
+
 template <int TYPE, bool LDSGEO>
 __global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launch_bounds__(LP_BLOCK) k_extend(SceneDev sc, FrameParams fp, PathBuffers pb, uint32_t iter,
                                                      unsigned long long *shard_stats, uint32_t stack_words)
@@ -238,32 +264,15 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launc
             return;
         }
     }
-    f3 o = mk3(orr.x, orr.y, orr.z), d = mk3(dm.x, dm.y, dm.z);
     uint32_t rng = __float_as_uint(orr.w);
     const uint32_t rng_in = rng;
-    const float eps = fp.pc.ray_epsilon;
-
-    float total = 0.0f;
-    Closest c;
-    c.t = LP_F32_MAX; c.u = 0.0f; c.v = 0.0f; c.tri = 0u; c.inst = HIT_MISS;
-    bool hit = false;
-    for (uint32_t k = 0; k < 128u; k++)   // MAX_OPACITY_BOUNCES (pathtracer.wgsl:1263)
-    {
-        c = scene_closest(geo, sc, lds_stack, o, d, eps);
-        hit = (c.t != LP_F32_MAX);
-        if (!hit) break;
-        total += c.t;
-        if (!(sc.instances[c.inst].flags & 1u)) break;
-        Surface s = resolve_surface(sc, c.inst, c.tri, c.u, c.v);
-        float opacity = surface_opacity(sc, s);
-        if (opacity < 1.0f && rnd(rng) >= opacity) o = add(o, scale(d, c.t));
-        else break;
-    }
-    pb.hit[slot] = make_float4(total, c.u, c.v, __uint_as_float(hit ? c.inst : HIT_MISS));
-    pb.hit_tri[slot] = c.tri;
+    float4 hitrec;
+    uint32_t hit_tri;
+    trace_alpha(geo, sc, lds_stack, mk3(orr.x, orr.y, orr.z), mk3(dm.x, dm.y, dm.z), rng, fp.pc.ray_epsilon, hitrec, hit_tri);
+    pb.hit[slot] = hitrec;
+    pb.hit_tri[slot] = hit_tri;
     if (rng != rng_in) pb.ori_rng[slot].w = __uint_as_float(rng);
 }
-
 
 // Persistent form of k_extend.  Rays of one wave need very different numbers of traversal steps (Cornell box:
 // 4 .. 25 node visits), so a one-ray-per-lane kernel keeps only ~36 % of the lanes busy (PMC: SQ_THREAD_CYCLES_VALU /
@@ -670,6 +679,91 @@ __device__ bool integrate_vertex(const Geo &geo, const SceneDev &sc, uint32_t *s
     return true;
 }
 
+// Everything of one integrator-loop iteration after the closest-hit query, for one path; writes the path state
+// back and returns whether the pixel still has work (the path continues, or its next camera sample was started).
+template <int TYPE, typename Geo>
+__device__ __forceinline__ bool shade_path(const Geo &geo, const SceneDev &sc, uint32_t *stack, const FrameParams &fp, PathBuffers &pb,
+                                           uint32_t slot, float4 orr, float4 dm, uint32_t rng, float4 hitrec, uint32_t hit_tri)
+{
+    bool alive = false;
+    float4 w4 = pb.weight[slot];
+    float4 r4 = pb.radiance[slot];
+    uint32_t meta = __float_as_uint(dm.w);
+
+    PathRegs p;
+    p.ori = mk3(orr.x, orr.y, orr.z);
+    p.dir = mk3(dm.x, dm.y, dm.z);
+    p.weight = mk3(w4.x, w4.y, w4.z);
+    p.radiance = mk3(r4.x, r4.y, r4.z);
+    p.rng = rng;
+    p.bounce = (int)(meta & META_BOUNCE_MASK);
+    p.in_medium = (meta & META_VOLUME) != 0;
+    p.next_emission = (meta & META_NEXT_EMISSION) != 0;
+    uint32_t sample = meta >> META_SAMPLE_SHIFT;
+    const bool was_in_medium = p.in_medium;
+    if (p.in_medium)
+    {
+        float4 a = pb.vol0[slot], b = pb.vol1[slot];
+        p.medium.density = mk3(a.x, a.y, a.z);
+        p.medium.anisotropy = a.w;
+        p.medium.scattering = mk3(b.x, b.y, b.z);
+    }
+    else { p.medium.density = splat(0.0f); p.medium.scattering = splat(0.0f); p.medium.anisotropy = 0.0f; }
+
+    bool cont = integrate_vertex<TYPE>(geo, sc, stack, fp, p, hitrec, hit_tri, pb, slot);
+    if (cont)
+    {
+        p.bounce++;
+        if (p.bounce > (int)fp.max_bounces) cont = false;   // loop condition `bounce <= MAX_BOUNCES` (:596)
+    }
+
+    if (cont)
+    {
+        alive = true;
+        if (p.in_medium && !was_in_medium)
+        {
+            pb.vol0[slot] = make_float4(p.medium.density.x, p.medium.density.y, p.medium.density.z, p.medium.anisotropy);
+            pb.vol1[slot] = make_float4(p.medium.scattering.x, p.medium.scattering.y, p.medium.scattering.z, 0.0f);
+        }
+        pb.weight[slot] = make_float4(p.weight.x, p.weight.y, p.weight.z, 0.0f);
+        if (p.radiance.x != r4.x || p.radiance.y != r4.y || p.radiance.z != r4.z)   // only emitters touch it
+            pb.radiance[slot] = make_float4(p.radiance.x, p.radiance.y, p.radiance.z, 0.0f);
+    }
+    else
+    {
+        // path finished: fold its radiance into the pixel, start the pixel's next sample (:234-239)
+        float4 c4 = pb.color[slot];
+        f3 cr = clamp_radiance(p.radiance, fp.pc.max_radiance);
+        pb.color[slot] = make_float4(c4.x + cr.x, c4.y + cr.y, c4.z + cr.z, 0.0f);
+        sample++;
+        if (sample < fp.spp)
+        {
+            alive = true;
+            uint32_t gx, gy;
+            slot_to_pixel(fp, slot, gx, gy);
+            camera_ray(fp, gx, gy, p.rng, p.ori, p.dir);
+            p.bounce = 0;
+            p.in_medium = false;
+            p.next_emission = true;
+            pb.weight[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+            pb.radiance[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (TYPE == LUPIN_PATHTRACE_MIS)
+            {
+                pb.next_hit[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(HIT_MISS));
+                pb.next_tri[slot] = 0u;
+            }
+        }
+    }
+    if (alive)
+    {
+        uint32_t nm = ((uint32_t)p.bounce & META_BOUNCE_MASK) | (p.in_medium ? META_VOLUME : 0u) |
+                      (p.next_emission ? META_NEXT_EMISSION : 0u) | (sample << META_SAMPLE_SHIFT);
+        pb.ori_rng[slot] = make_float4(p.ori.x, p.ori.y, p.ori.z, __uint_as_float(p.rng));
+        pb.dir_meta[slot] = make_float4(p.dir.x, p.dir.y, p.dir.z, __uint_as_float(nm));
+    }
+    return alive;
+}
+
 template <int TYPE, bool LDSGEO>
 __global__ void __attribute__((amdgpu_waves_per_eu(TYPE == 0 || TYPE == 2 ? LP_SHADE_WAVES : 1, 8))) __launch_bounds__(LP_BLOCK) k_shade(SceneDev sc, FrameParams fp, PathBuffers pb, uint32_t iter,
                                                     unsigned long long *shard_stats, uint32_t stack_words)
@@ -684,85 +778,48 @@ __global__ void __attribute__((amdgpu_waves_per_eu(TYPE == 0 || TYPE == 2 ? LP_S
     if (i < count)
     {
         slot = pb.queue[iter & 1][(size_t)shard * pb.shard_cap + i];
-        float4 orr = pb.ori_rng[slot];
-        float4 dm = pb.dir_meta[slot];
-        float4 w4 = pb.weight[slot];
-        float4 r4 = pb.radiance[slot];
-        uint32_t meta = __float_as_uint(dm.w);
-
-        PathRegs p;
-        p.ori = mk3(orr.x, orr.y, orr.z);
-        p.dir = mk3(dm.x, dm.y, dm.z);
-        p.weight = mk3(w4.x, w4.y, w4.z);
-        p.radiance = mk3(r4.x, r4.y, r4.z);
-        p.rng = __float_as_uint(orr.w);
-        p.bounce = (int)(meta & META_BOUNCE_MASK);
-        p.in_medium = (meta & META_VOLUME) != 0;
-        p.next_emission = (meta & META_NEXT_EMISSION) != 0;
-        uint32_t sample = meta >> META_SAMPLE_SHIFT;
-        const bool was_in_medium = p.in_medium;
-        if (p.in_medium)
-        {
-            float4 a = pb.vol0[slot], b = pb.vol1[slot];
-            p.medium.density = mk3(a.x, a.y, a.z);
-            p.medium.anisotropy = a.w;
-            p.medium.scattering = mk3(b.x, b.y, b.z);
-        }
-        else { p.medium.density = splat(0.0f); p.medium.scattering = splat(0.0f); p.medium.anisotropy = 0.0f; }
-
-        bool cont = integrate_vertex<TYPE>(geo, sc, lds_stack, fp, p, pb.hit[slot], pb.hit_tri[slot], pb, slot);
-        if (cont)
-        {
-            p.bounce++;
-            if (p.bounce > (int)fp.max_bounces) cont = false;   // loop condition `bounce <= MAX_BOUNCES` (:596)
-        }
-
-        if (cont)
-        {
-            alive = true;
-            if (p.in_medium && !was_in_medium)
-            {
-                pb.vol0[slot] = make_float4(p.medium.density.x, p.medium.density.y, p.medium.density.z, p.medium.anisotropy);
-                pb.vol1[slot] = make_float4(p.medium.scattering.x, p.medium.scattering.y, p.medium.scattering.z, 0.0f);
-            }
-            pb.weight[slot] = make_float4(p.weight.x, p.weight.y, p.weight.z, 0.0f);
-            pb.radiance[slot] = make_float4(p.radiance.x, p.radiance.y, p.radiance.z, 0.0f);
-        }
-        else
-        {
-            // path finished: fold its radiance into the pixel, start the pixel's next sample (:234-239)
-            float4 c4 = pb.color[slot];
-            f3 cr = clamp_radiance(p.radiance, fp.pc.max_radiance);
-            pb.color[slot] = make_float4(c4.x + cr.x, c4.y + cr.y, c4.z + cr.z, 0.0f);
-            sample++;
-            if (sample < fp.spp)
-            {
-                alive = true;
-                uint32_t gx, gy;
-                slot_to_pixel(fp, slot, gx, gy);
-                camera_ray(fp, gx, gy, p.rng, p.ori, p.dir);
-                p.bounce = 0;
-                p.in_medium = false;
-                p.next_emission = true;
-                pb.weight[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-                pb.radiance[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (TYPE == LUPIN_PATHTRACE_MIS)
-                {
-                    pb.next_hit[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(HIT_MISS));
-                    pb.next_tri[slot] = 0u;
-                }
-            }
-        }
-        if (alive)
-        {
-            uint32_t nm = ((uint32_t)p.bounce & META_BOUNCE_MASK) | (p.in_medium ? META_VOLUME : 0u) |
-                          (p.next_emission ? META_NEXT_EMISSION : 0u) | (sample << META_SAMPLE_SHIFT);
-            pb.ori_rng[slot] = make_float4(p.ori.x, p.ori.y, p.ori.z, __uint_as_float(p.rng));
-            pb.dir_meta[slot] = make_float4(p.dir.x, p.dir.y, p.dir.z, __uint_as_float(nm));
-        }
+        const float4 orr = pb.ori_rng[slot];
+        alive = shade_path<TYPE>(geo, sc, lds_stack, fp, pb, slot, orr, pb.dir_meta[slot], __float_as_uint(orr.w), pb.hit[slot], pb.hit_tri[slot]);
     }
     if (i == 0 && iter == 0) shard_stats[shard * 2 + 1] += (unsigned long long)count * fp.spp;
+    queue_append(alive, slot, pb.queue[(iter + 1) & 1] + (size_t)shard * pb.shard_cap, &pb.counts[(iter + 1) * LP_SHARDS + shard]);
+}
 
+// Fused stage: trace + shade of one bounce in one kernel.  The hit record never goes to memory and the ray is read
+// once: 270 -> ~150 B of HBM traffic per path-bounce and half the launches, at the price of tracing at the shade
+// kernel's register budget.  Selected with LUPIN_PIPELINE=fused (see DESIGN.md for the A/B numbers).
+template <int TYPE, bool LDSGEO>
+__global__ void __attribute__((amdgpu_waves_per_eu(TYPE == 0 || TYPE == 2 ? LP_SHADE_WAVES : 1, 8))) __launch_bounds__(LP_BLOCK) k_bounce(SceneDev sc, FrameParams fp, PathBuffers pb, uint32_t iter,
+                                                     unsigned long long *shard_stats, uint32_t stack_words)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+    const auto geo = make_geo<LDSGEO>(sc, lds_stack, stack_words);
+    const uint32_t shard = blockIdx.x % LP_SHARDS;
+    const uint32_t count = pb.counts[iter * LP_SHARDS + shard];
+    const uint32_t i = (blockIdx.x / LP_SHARDS) * LP_BLOCK + threadIdx.x;
+    if (i == 0 && count)
+    {
+        shard_stats[shard * 2 + 0] += count;
+        if (iter == 0) shard_stats[shard * 2 + 1] += (unsigned long long)count * fp.spp;
+    }
+    bool alive = false;
+    uint32_t slot = 0;
+    if (i < count)
+    {
+        slot = pb.queue[iter & 1][(size_t)shard * pb.shard_cap + i];
+        const float4 orr = pb.ori_rng[slot];
+        const float4 dm = pb.dir_meta[slot];
+        uint32_t rng = __float_as_uint(orr.w);
+        float4 hitrec;
+        uint32_t hit_tri;
+        if (TYPE == LUPIN_PATHTRACE_MIS && !(__float_as_uint(dm.w) & META_NEXT_EMISSION))
+        {
+            hitrec = pb.next_hit[slot];
+            hit_tri = pb.next_tri[slot];
+        }
+        else trace_alpha(geo, sc, lds_stack, mk3(orr.x, orr.y, orr.z), mk3(dm.x, dm.y, dm.z), rng, fp.pc.ray_epsilon, hitrec, hit_tri);
+        alive = shade_path<TYPE>(geo, sc, lds_stack, fp, pb, slot, orr, dm, rng, hitrec, hit_tri);
+    }
     queue_append(alive, slot, pb.queue[(iter + 1) & 1] + (size_t)shard * pb.shard_cap, &pb.counts[(iter + 1) * LP_SHARDS + shard]);
 }
 
@@ -892,6 +949,7 @@ struct LupinContext
     unsigned long long *stat_counters = nullptr;   // per shard: [2s] path bounces, [2s+1] paths
     bool timing = false;
     int store_rounding = 0;        // LUPIN_STORE_ROUND_TOWARD_ZERO
+    bool fused_pipeline = false;    // LUPIN_PIPELINE=fused: one trace+shade kernel per bounce instead of two stages
     bool lds_geometry = true;       // LUPIN_LDS_GEOMETRY=0 keeps small scenes in global memory (A/B runs)
     bool persistent_extend = false; // LUPIN_EXTEND=persistent selects the lane-refill kernel (measured slower)
     uint32_t resident_blocks = 1024;
@@ -1011,6 +1069,19 @@ static void launch_iteration_t(LupinContext *ctx, const LupinScene *scene, const
 {
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     if (ctx->timing) { e0 = get_event(ctx); e1 = get_event(ctx); e2 = get_event(ctx); hipEventRecord(e0, ctx->stream); }
+    if (ctx->fused_pipeline)
+    {
+        hipLaunchKernelGGL((k_bounce<TYPE, LDSGEO>), dim3(blocks), dim3(LP_BLOCK), lds, ctx->stream, scene->dev, fp, ctx->pb, iter, ctx->stat_counters, stack_words);
+        if (ctx->timing)
+        {
+            hipEventRecord(e1, ctx->stream);
+            hipEventRecord(e2, ctx->stream);
+            ctx->ev_extend.push_back({e0, e1});   // the fused kernel is booked as "extend"; "shade" stays ~0
+            ctx->ev_shade.push_back({e1, e2});
+        }
+        ctx->extend_launches++;
+        return;
+    }
     if (ctx->persistent_extend && !LDSGEO)
         hipLaunchKernelGGL(k_extend_persistent<TYPE>, dim3(ctx->resident_blocks), dim3(LP_BLOCK), lds, ctx->stream,
                            scene->dev, fp, ctx->pb, iter, ctx->stat_counters);
@@ -1061,6 +1132,8 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
     hipMemsetAsync(ctx->stat_counters, 0, 2 * LP_SHARDS * sizeof(unsigned long long), ctx->stream);
     const char *ext = getenv("LUPIN_EXTEND");
     ctx->persistent_extend = (ext && strcmp(ext, "persistent") == 0);
+    const char *pl = getenv("LUPIN_PIPELINE");
+    ctx->fused_pipeline = (pl && strcmp(pl, "fused") == 0);
     const char *lg = getenv("LUPIN_LDS_GEOMETRY");
     ctx->lds_geometry = !(lg && strcmp(lg, "0") == 0);
     hipDeviceProp_t prop;
