@@ -437,7 +437,8 @@ LP_DEV Closest scene_closest(const Geo &geo, const SceneDev &sc, uint32_t *stack
             cd = mk3(d.x * in.r0.x + d.y * in.r0.y + d.z * in.r0.z + 0.0f * in.r0.w,
                      d.x * in.r1.x + d.y * in.r1.y + d.z * in.r1.z + 0.0f * in.r1.w,
                      d.x * in.r2.x + d.y * in.r2.y + d.z * in.r2.z + 0.0f * in.r2.w);
-            cinv = mk3(1.0f / cd.x, 1.0f / cd.y, 1.0f / cd.z);
+            // the reciprocal direction only feeds box tests: a BLAS whose root is a leaf (quads, small meshes) needs none
+            if (!(in.blas_root & REF_LEAF)) cinv = mk3(1.0f / cd.x, 1.0f / cd.y, 1.0f / cd.z);
             blas_base = sp;
             cur = in.blas_root;
         }
@@ -1415,9 +1416,11 @@ LP_FN float lights_pdf(const Geo &geo, const SceneDev &sc, uint32_t *stack, f3 p
             f3 ld = mk3(in.r0.x * incoming.x + in.r0.y * incoming.y + in.r0.z * incoming.z + in.r0.w * 0.0f,
                         in.r1.x * incoming.x + in.r1.y * incoming.y + in.r1.z * incoming.z + in.r1.w * 0.0f,
                         in.r2.x * incoming.x + in.r2.y * incoming.y + in.r2.z * incoming.z + in.r2.w * 0.0f);
-            f3 linv = mk3(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
             Closest c;
             c.t = LP_F32_MAX; c.u = 0.0f; c.v = 0.0f; c.tri = 0u; c.inst = 0u;
+            // emissive meshes are mostly quads whose BLAS is a single leaf: no box test, so no reciprocal direction
+            f3 linv = splat(0.0f);
+            if (!(in.blas_root & REF_LEAF)) linv = mk3(1.0f / ld.x, 1.0f / ld.y, 1.0f / ld.z);
             blas_closest(geo, stack, 0u, in.blas_root, lo, ld, linv, eps, c);
             if (c.t == LP_F32_MAX) break;
             f3 ln = geometric_normal(geo, in, c.tri);

@@ -481,6 +481,131 @@ def load_scene_yoctogl_v24(path, ctx, build_both_bvhs=True, asset_dirs: Sequence
     return api.build_accel_structures_and_upload(ctx, scene_cpu, textures, envs_info, build_both_bvhs), cams
 
 
+def build_scene_bistro_class_cpu(asset_dir, seed=0xB157, n_meshes=20, n_instances=400, n_lights=100, n_materials=60):
+    """Seeded procedural stand-in for the 'bistroexterior' config (the real scene is not
+    available offline): `n_meshes` jittered copies of bunny.ply (144 046 triangles each, ~2.9 M unique triangles at
+    the default), instanced `n_instances` times on a street-like grid with random scale / yaw, `n_materials`
+    materials cycling through every material type, `n_lights` small emissive quads (street lamps / windows), a
+    textured ground quad and the sky.hdr environment.  Deterministic in `seed`.
+    Returns (SceneCPU, textures, envs_info, cameras)."""
+    rng = np.random.default_rng(seed)
+    scene = api.SceneCPU()
+    base = api.SceneCPU()
+    load_mesh_ply(os.path.join(asset_dir, "shapes", "bunny.ply"), base)
+    bpos, bidx = base.verts_pos_array[0], base.indices_array[0]
+    bnrm = base.verts_normal_array[0] if base.verts_normal_array else None
+    lo, hi = bpos[:, :3].min(0), bpos[:, :3].max(0)
+    centre, extent = (lo + hi) / 2, float((hi - lo).max())
+
+    infos = []
+    for m in range(n_meshes):
+        # low-frequency warp: every copy is a different mesh with its own BVH
+        k = rng.uniform(2.0, 9.0, 3) / extent
+        ph = rng.uniform(0, 2 * np.pi, 3)
+        amp = rng.uniform(0.01, 0.04) * extent
+        p = bpos.copy()
+        q = bpos[:, :3] - centre
+        p[:, 0] += (amp * np.sin(k[0] * q[:, 1] + ph[0])).astype(np.float32)
+        p[:, 1] += (amp * np.sin(k[1] * q[:, 2] + ph[1])).astype(np.float32)
+        p[:, 2] += (amp * np.sin(k[2] * q[:, 0] + ph[2])).astype(np.float32)
+        scene.verts_pos_array.append(p.astype(np.float32))
+        scene.indices_array.append(bidx.copy())
+        info = api.default_mesh_info()
+        if bnrm is not None and m % 2 == 0:   # half the meshes shade with vertex normals, half with geometric ones
+            scene.verts_normal_array.append(bnrm.copy())
+            info["normals_buf_idx"] = len(scene.verts_normal_array) - 1
+        infos.append(info)
+    # ground quad (textured) and a unit light quad
+    ground = len(infos)
+    g = np.zeros((4, 4), np.float32)
+    g[:, :3] = [(-1, 0, 1), (1, 0, 1), (1, 0, -1), (-1, 0, -1)]
+    scene.verts_pos_array.append(g)
+    scene.indices_array.append(np.array([0, 1, 2, 2, 3, 0], np.uint32))
+    scene.verts_texcoord_array.append(np.array([(0, 0), (40, 0), (40, 40), (0, 40)], np.float32))
+    gi = api.default_mesh_info()
+    gi["texcoords_buf_idx"] = 0
+    infos.append(gi)
+    quad = len(infos)
+    qv = np.zeros((4, 4), np.float32)
+    qv[:, :3] = [(-0.5, 0, -0.5), (-0.5, 0, 0.5), (0.5, 0, 0.5), (0.5, 0, -0.5)]
+    scene.verts_pos_array.append(qv)
+    scene.indices_array.append(np.array([0, 2, 1, 2, 0, 3], np.uint32))
+    infos.append(api.default_mesh_info())
+    scene.mesh_infos = np.array(infos, MESH_INFO_DTYPE)
+
+    mats = []
+    for i in range(n_materials):
+        m = api.default_material()
+        t = i % 8
+        m["mat_type"] = t
+        m["color"] = (*rng.uniform(0.25, 0.95, 3), 1.0)
+        m["roughness"] = [0.0, 0.2, 0.15, 0.0, 0.0, 0.1, 0.0, 0.3][t] + (rng.uniform(0, 0.2) if t in (1, 2, 7) else 0.0)
+        m["metallic"] = rng.uniform(0, 1) if t == 7 else 0.0
+        m["ior"] = 1.5
+        if t in (4, 5, 6):
+            m["scattering"][:3] = rng.uniform(0.1, 0.9, 3)
+            m["tr_depth"] = 0.05
+        mats.append(m)
+    ground_mat = len(mats)
+    gm = api.default_material()
+    gm["color"] = (0.7, 0.7, 0.7, 1.0)
+    gm["color_tex_idx"] = 0
+    mats.append(gm)
+    light_mats = []
+    for i in range(8):
+        lm = api.default_material()
+        lm["emission"][:3] = rng.uniform(8.0, 30.0) * np.array([1.0, rng.uniform(0.7, 1.0), rng.uniform(0.4, 1.0)])
+        light_mats.append(len(mats))
+        mats.append(lm)
+    scene.materials = np.array(mats, MATERIAL_DTYPE)
+
+    def frame(scale, yaw, pos):
+        c, s_ = np.cos(yaw), np.sin(yaw)
+        f = np.zeros((4, 3), np.float32)
+        f[0] = (scale * c, 0, -scale * s_)
+        f[1] = (0, scale, 0)
+        f[2] = (scale * s_, 0, scale * c)
+        f[3] = pos
+        return f
+
+    insts = []
+    side = int(np.ceil(np.sqrt(n_instances)))
+    spacing = 1.6
+    unit = 1.0 / extent
+    for i in range(n_instances):
+        gx, gz = i % side, i // side
+        sc_ = unit * rng.uniform(0.6, 1.4)
+        pos = np.array([(gx - side / 2) * spacing + rng.uniform(-0.3, 0.3), 0.0, gz * spacing + rng.uniform(-0.3, 0.3) + 2.0])
+        pos[1] = -lo[1] * sc_
+        fr = frame(sc_, rng.uniform(0, 2 * np.pi), pos - centre * np.array([sc_, 0, sc_]) * np.array([1, 0, 1]))
+        insts.append(api.instance_from_transform(fr, int(rng.integers(0, n_meshes)), int(rng.integers(0, n_materials))))
+    half = side * spacing
+    insts.append(api.instance_from_transform(frame(half, 0.0, np.array([0.0, 0.0, half * 0.5 + 1.0])), ground, ground_mat))
+    for i in range(n_lights):
+        pos = np.array([rng.uniform(-half / 2, half / 2), rng.uniform(1.5, 3.0), rng.uniform(2.0, side * spacing)])
+        insts.append(api.instance_from_transform(frame(rng.uniform(0.15, 0.4), rng.uniform(0, 2 * np.pi), pos), quad,
+                                                 light_mats[int(rng.integers(0, len(light_mats)))]))
+    scene.instances = np.array(insts, INSTANCE_DTYPE)
+
+    env = api.default_environment()
+    env["emission"] = (0.35, 0.35, 0.4)
+    env["emission_tex_idx"] = 1
+    scene.environments = np.array([env], ENVIRONMENT_DTYPE)
+    floor_px, _ = load_texture_pixels(os.path.join(asset_dir, "textures", "floor.png"))
+    sky_px, sky_f32 = load_texture_pixels(os.path.join(asset_dir, "textures", "sky.hdr"))
+    textures = [api.TextureCPU(floor_px), api.TextureCPU(sky_px)]
+    envs_info = [api.EnvMapInfo(np.ascontiguousarray(sky_f32, np.float32), sky_f32.shape[1], sky_f32.shape[0])]
+    cam = SceneCamera(transform=np.array([[1, 0, 0], [0, 0.94, 0.34], [0, -0.34, 0.94], [0, 2.6, -3.0]], np.float32),
+                      params=api.CameraParams(lens=0.035, film=0.036, aspect=16 / 9, focus=10000.0, aperture=0.0))
+    api.validate_scene(scene, len(textures), len(textures))
+    return scene, textures, envs_info, [cam]
+
+
+def build_scene_bistro_class(ctx, asset_dir, **kw):
+    scene_cpu, textures, envs_info, cams = build_scene_bistro_class_cpu(asset_dir, **kw)
+    return api.build_accel_structures_and_upload(ctx, scene_cpu, textures, envs_info, True), cams
+
+
 def compute_dimensions_for_1080p(aspect):
     """lupin_tests/src/main.rs:477-484"""
     if aspect < 1.0:

@@ -39,7 +39,7 @@ SCENE_CASES = [("cornellbox", 0, 0), ("materials1", 0, 0), ("materials2", 1, 0),
                ("materials5", 1, 0), ("environments1", 1, 0), ("environments2", 2, 0), ("features1", 1, 0), ("shapes1", 1, 0),
                ("instances1", 1, 0), ("arealights1", 2, 0), ("furnace1", 0, 0), ("furnace2", 0, 0),
                ("materials4", 1, 1), ("materials4", 1, 2), ("materials4", 1, 3), ("environments1", 2, 1), ("features1", 2, 3),
-               ("materials2", 2, 1)]
+               ("materials2", 2, 1), ("bistro_class_small", 0, 0), ("bistro_class_small", 0, 1)]
 
 
 @pytest.mark.parametrize("name,cam_i,ptype", SCENE_CASES)

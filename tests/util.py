@@ -18,6 +18,10 @@ def load_scene(name, ctx=None):
     if key not in _scene_cache:
         if name == "cornellbox_builtin":
             _scene_cache[key] = loader.build_scene_cornell_box(ctx)
+        elif name.startswith("bistro_class"):
+            # "bistro_class" = full stand-in (20 meshes / 400 instances / 100 lights); "bistro_class_small" for tests
+            kw = dict(n_meshes=3, n_instances=40, n_lights=12, n_materials=24) if name.endswith("small") else {}
+            _scene_cache[key] = loader.build_scene_bistro_class(ctx, SHARED, **kw)
         else:
             path = os.path.join(SCENES, name, name + ".json")
             _scene_cache[key] = loader.load_scene_yoctogl_v24(path, ctx, asset_dirs=[SHARED])
