@@ -38,6 +38,7 @@ using namespace lpd;
 constexpr uint32_t META_BOUNCE_MASK = 0xFFFu;
 constexpr uint32_t META_VOLUME = 1u << 12;         // volume_stack_len == 1
 constexpr uint32_t META_NEXT_EMISSION = 1u << 13;  // MIS / Direct `next_emission`
+constexpr uint32_t META_TERMINATED = 1u << 14;     // MIS / Direct: the path ended in k_shade; k_shadow folds it after its shadow rays
 constexpr uint32_t META_SAMPLE_SHIFT = 16;
 constexpr uint32_t HIT_MISS = 0xFFFFFFFFu;
 
@@ -54,6 +55,12 @@ struct PathBuffers
     float4 *vol1;       // medium scattering.xyz
     float4 *next_hit;   // MIS: hit of the BSDF-sampled shadow ray, reused as next vertex
     uint32_t *next_tri;
+    // MIS / Direct shadow rays, recorded by k_shade and traced by k_shadow (radiance += factor * emission (*|/) scalar)
+    float4 *sh_org;     // origin.xyz | flags (bit0: ray 0 valid, bit1: ray 1 valid)
+    float4 *sh_d0;      // ray 0 direction | scalar 0
+    float4 *sh_f0;      // ray 0 factor = weight * bsdfcos
+    float4 *sh_d1;      // ray 1 direction | scalar 1
+    float4 *sh_f1;      // ray 1 factor
     // Live-path queues, sharded: one global counter per iteration would serialise every wave's append on a
     // single L2 atomic (~88 per microsecond chip-wide -- measured: 186 us per 1M-path iteration, more than the
     // shading itself).  Each of LP_SHARDS shards owns a fixed segment of the queue and its own counter; block b
@@ -470,6 +477,14 @@ __device__ __forceinline__ f3 clamp_radiance(f3 r, float max_radiance)
     return r;
 }
 
+// shadow rays a vertex wants traced (MIS: BSDF- and light-sampled directions; Direct: the light ray)
+struct ShadowRays
+{
+    f3 org;
+    f3 d0, f0; float s0; bool v0;
+    f3 d1, f1; float s1; bool v1;
+};
+
 struct PathRegs
 {
     f3 ori, dir, weight, radiance;
@@ -486,7 +501,7 @@ struct PathRegs
 //      2: pathtrace_naive (:942-1059)     3: pathtrace_direct (:1062-1245)
 template <int TYPE, typename Geo>
 __device__ bool integrate_vertex(const Geo &geo, const SceneDev &sc, uint32_t *stack, const FrameParams &fp, PathRegs &p,
-                                 float4 hitrec, uint32_t hit_tri, PathBuffers &pb, uint32_t slot)
+                                 float4 hitrec, uint32_t hit_tri, ShadowRays &sh)
 {
     const float eps = fp.pc.ray_epsilon;
     const uint32_t hit_inst = __float_as_uint(hitrec.w);
@@ -536,13 +551,8 @@ __device__ bool integrate_vertex(const Geo &geo, const SceneDev &sc, uint32_t *s
                 f3 bsdfcos = bsdf_eval(mp, normal, outgoing, li);
                 if (none_zero3(bsdfcos) && pdf > 0.0f)
                 {
-                    Closest lc = scene_closest(geo, sc, stack, hit_pos, li, eps);
-                    f3 emission;
-                    if (lc.t != LP_F32_MAX)
-                        emission = material_point(sc, resolve_surface(sc, lc.inst, lc.tri, lc.u, lc.v)).emission;
-                    else
-                        emission = environment_radiance(sc, li);
-                    p.radiance = add(p.radiance, divs(mul(mul(p.weight, bsdfcos), emission), pdf));
+                    // radiance += weight * bsdfcos * emission(light_ray) / pdf   -- traced by k_shadow (:1125-1138)
+                    sh.org = hit_pos; sh.d1 = li; sh.f1 = mul(p.weight, bsdfcos); sh.s1 = pdf; sh.v1 = true;
                 }
                 p.next_emission = false;
             }
@@ -575,6 +585,7 @@ __device__ bool integrate_vertex(const Geo &geo, const SceneDev &sc, uint32_t *s
             }
             else   // MIS: BSDF sample then light sample, power heuristic (:802-855)
             {
+                #pragma unroll 1
                 for (int k = 0; k < 2; k++)
                 {
                     const bool light_turn = (k != 0);
@@ -598,18 +609,11 @@ __device__ bool integrate_vertex(const Geo &geo, const SceneDev &sc, uint32_t *s
 
                     if (none_zero3(bsdfcos) && mis_w != 0.0f)
                     {
-                        Closest mc = scene_closest(geo, sc, stack, hit_pos, mi, eps);
-                        const bool mhit = mc.t != LP_F32_MAX;
-                        if (!light_turn)
-                        {
-                            pb.next_hit[slot] = make_float4(mhit ? mc.t : 0.0f, mhit ? mc.u : 0.0f, mhit ? mc.v : 0.0f,
-                                                            __uint_as_float(mhit ? mc.inst : HIT_MISS));
-                            pb.next_tri[slot] = mc.tri;
-                        }
-                        f3 emission;
-                        if (mhit) emission = material_point(sc, resolve_surface(sc, mc.inst, mc.tri, mc.u, mc.v)).emission;
-                        else emission = environment_radiance(sc, mi);
-                        p.radiance = add(p.radiance, scale(mul(mul(p.weight, bsdfcos), emission), mis_w));
+                        // radiance += weight * bsdfcos * emission(mis_ray) * mis_weight   -- traced by k_shadow (:831-849);
+                        // the BSDF-sampled ray's hit also becomes `next_intersection`
+                        sh.org = hit_pos;
+                        if (!light_turn) { sh.d0 = mi; sh.f0 = mul(p.weight, bsdfcos); sh.s0 = mis_w; sh.v0 = true; }
+                        else             { sh.d1 = mi; sh.f1 = mul(p.weight, bsdfcos); sh.s1 = mis_w; sh.v1 = true; }
                     }
                 }
                 p.weight = mul(p.weight, divs(bsdf_eval(mp, normal, outgoing, incoming), bsdf_pdf(mp, normal, outgoing, incoming)));
@@ -710,11 +714,35 @@ __device__ __forceinline__ bool shade_path(const Geo &geo, const SceneDev &sc, u
     }
     else { p.medium.density = splat(0.0f); p.medium.scattering = splat(0.0f); p.medium.anisotropy = 0.0f; }
 
-    bool cont = integrate_vertex<TYPE>(geo, sc, stack, fp, p, hitrec, hit_tri, pb, slot);
+    ShadowRays sh;
+    sh.v0 = sh.v1 = false;
+    bool cont = integrate_vertex<TYPE>(geo, sc, stack, fp, p, hitrec, hit_tri, sh);
     if (cont)
     {
         p.bounce++;
         if (p.bounce > (int)fp.max_bounces) cont = false;   // loop condition `bounce <= MAX_BOUNCES` (:596)
+    }
+
+    if (TYPE == LUPIN_PATHTRACE_MIS || TYPE == LUPIN_PATHTRACE_DIRECT)
+    {
+        // hand the vertex to k_shadow: it adds the shadow-ray terms to `radiance` (the order of the additions is the
+        // reference's) and only then folds a finished path into the pixel / starts the next sample
+        if (p.in_medium && !was_in_medium)
+        {
+            pb.vol0[slot] = make_float4(p.medium.density.x, p.medium.density.y, p.medium.density.z, p.medium.anisotropy);
+            pb.vol1[slot] = make_float4(p.medium.scattering.x, p.medium.scattering.y, p.medium.scattering.z, 0.0f);
+        }
+        pb.weight[slot] = make_float4(p.weight.x, p.weight.y, p.weight.z, 0.0f);
+        pb.radiance[slot] = make_float4(p.radiance.x, p.radiance.y, p.radiance.z, 0.0f);
+        const uint32_t nm = ((uint32_t)p.bounce & META_BOUNCE_MASK) | (p.in_medium ? META_VOLUME : 0u) |
+                            (p.next_emission ? META_NEXT_EMISSION : 0u) | (cont ? 0u : META_TERMINATED) | (sample << META_SAMPLE_SHIFT);
+        pb.ori_rng[slot] = make_float4(p.ori.x, p.ori.y, p.ori.z, __uint_as_float(p.rng));
+        pb.dir_meta[slot] = make_float4(p.dir.x, p.dir.y, p.dir.z, __uint_as_float(nm));
+        const uint32_t flags = (sh.v0 ? 1u : 0u) | (sh.v1 ? 2u : 0u);
+        pb.sh_org[slot] = make_float4(sh.org.x, sh.org.y, sh.org.z, __uint_as_float(flags));
+        if (sh.v0) { pb.sh_d0[slot] = make_float4(sh.d0.x, sh.d0.y, sh.d0.z, sh.s0); pb.sh_f0[slot] = make_float4(sh.f0.x, sh.f0.y, sh.f0.z, 0.0f); }
+        if (sh.v1) { pb.sh_d1[slot] = make_float4(sh.d1.x, sh.d1.y, sh.d1.z, sh.s1); pb.sh_f1[slot] = make_float4(sh.f1.x, sh.f1.y, sh.f1.z, 0.0f); }
+        return true;
     }
 
     if (cont)
@@ -765,7 +793,7 @@ __device__ __forceinline__ bool shade_path(const Geo &geo, const SceneDev &sc, u
 }
 
 template <int TYPE, bool LDSGEO>
-__global__ void __attribute__((amdgpu_waves_per_eu(TYPE == 0 || TYPE == 2 ? LP_SHADE_WAVES : 1, 8))) __launch_bounds__(LP_BLOCK) k_shade(SceneDev sc, FrameParams fp, PathBuffers pb, uint32_t iter,
+__global__ void __attribute__((amdgpu_waves_per_eu(TYPE == 1 ? 1 : LP_SHADE_WAVES, 8))) __launch_bounds__(LP_BLOCK) k_shade(SceneDev sc, FrameParams fp, PathBuffers pb, uint32_t iter,
                                                     unsigned long long *shard_stats, uint32_t stack_words)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
@@ -782,43 +810,98 @@ __global__ void __attribute__((amdgpu_waves_per_eu(TYPE == 0 || TYPE == 2 ? LP_S
         alive = shade_path<TYPE>(geo, sc, lds_stack, fp, pb, slot, orr, pb.dir_meta[slot], __float_as_uint(orr.w), pb.hit[slot], pb.hit_tri[slot]);
     }
     if (i == 0 && iter == 0) shard_stats[shard * 2 + 1] += (unsigned long long)count * fp.spp;
+    if (TYPE == LUPIN_PATHTRACE_MIS || TYPE == LUPIN_PATHTRACE_DIRECT) return;   // k_shadow appends
     queue_append(alive, slot, pb.queue[(iter + 1) & 1] + (size_t)shard * pb.shard_cap, &pb.counts[(iter + 1) * LP_SHARDS + shard]);
 }
 
-// Fused stage: trace + shade of one bounce in one kernel.  The hit record never goes to memory and the ray is read
-// once: 270 -> ~150 B of HBM traffic per path-bounce and half the launches, at the price of tracing at the shade
-// kernel's register budget.  Selected with LUPIN_PIPELINE=fused (see DESIGN.md for the A/B numbers).
+// emission of a surface point: emission_sample * mat.emission of get_material_point (pathtracer.wgsl:1295-1298,1315)
+__device__ __forceinline__ f3 surface_emission(const SceneDev &sc, const Surface &s)
+{
+    const LupinMaterial *m = &sc.materials[s.in.mat_idx];
+    f3 es = splat(1.0f);
+    if (s.mesh.texcoords_base != LUPIN_SENTINEL_IDX && m->emission_tex_idx != LUPIN_SENTINEL_IDX)
+    {
+        float tu, tv;
+        interp_texcoords(sc, s, tu, tv);
+        float4 t = sample_texture(sc, m->emission_tex_idx, tu, tv);
+        es = mk3(t.x, t.y, t.z);
+    }
+    return mk3(es.x * m->emission[0], es.y * m->emission[1], es.z * m->emission[2]);
+}
+
+// Shadow-ray stage of the MIS and Direct integrators: traces the rays k_shade recorded (plain closest hit, no alpha
+// skipping -- pathtracer.wgsl:834,1126), adds their terms to the path radiance in the reference's order, keeps the
+// BSDF-sampled hit as MIS `next_intersection`, and finishes paths that ended at this vertex.
 template <int TYPE, bool LDSGEO>
-__global__ void __attribute__((amdgpu_waves_per_eu(TYPE == 0 || TYPE == 2 ? LP_SHADE_WAVES : 1, 8))) __launch_bounds__(LP_BLOCK) k_bounce(SceneDev sc, FrameParams fp, PathBuffers pb, uint32_t iter,
-                                                     unsigned long long *shard_stats, uint32_t stack_words)
+__global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launch_bounds__(LP_BLOCK) k_shadow(SceneDev sc, FrameParams fp, PathBuffers pb, uint32_t iter,
+                                                     uint32_t stack_words)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     const auto geo = make_geo<LDSGEO>(sc, lds_stack, stack_words);
     const uint32_t shard = blockIdx.x % LP_SHARDS;
     const uint32_t count = pb.counts[iter * LP_SHARDS + shard];
     const uint32_t i = (blockIdx.x / LP_SHARDS) * LP_BLOCK + threadIdx.x;
-    if (i == 0 && count)
-    {
-        shard_stats[shard * 2 + 0] += count;
-        if (iter == 0) shard_stats[shard * 2 + 1] += (unsigned long long)count * fp.spp;
-    }
     bool alive = false;
     uint32_t slot = 0;
     if (i < count)
     {
         slot = pb.queue[iter & 1][(size_t)shard * pb.shard_cap + i];
-        const float4 orr = pb.ori_rng[slot];
-        const float4 dm = pb.dir_meta[slot];
-        uint32_t rng = __float_as_uint(orr.w);
-        float4 hitrec;
-        uint32_t hit_tri;
-        if (TYPE == LUPIN_PATHTRACE_MIS && !(__float_as_uint(dm.w) & META_NEXT_EMISSION))
+        const float eps = fp.pc.ray_epsilon;
+        const float4 so = pb.sh_org[slot];
+        const uint32_t flags = __float_as_uint(so.w);
+        const f3 org = mk3(so.x, so.y, so.z);
+        const float4 r4 = pb.radiance[slot];
+        f3 radiance = mk3(r4.x, r4.y, r4.z);
+        for (int k = 0; k < 2; k++)
         {
-            hitrec = pb.next_hit[slot];
-            hit_tri = pb.next_tri[slot];
+            if (!(flags & (1u << k))) continue;
+            const float4 dd = k ? pb.sh_d1[slot] : pb.sh_d0[slot];
+            const float4 ff = k ? pb.sh_f1[slot] : pb.sh_f0[slot];
+            const f3 dir = mk3(dd.x, dd.y, dd.z);
+            const Closest c = scene_closest(geo, sc, lds_stack, org, dir, eps);
+            const bool hit = c.t != LP_F32_MAX;
+            if (TYPE == LUPIN_PATHTRACE_MIS && k == 0)
+            {
+                pb.next_hit[slot] = make_float4(hit ? c.t : 0.0f, hit ? c.u : 0.0f, hit ? c.v : 0.0f, __uint_as_float(hit ? c.inst : HIT_MISS));
+                pb.next_tri[slot] = c.tri;
+            }
+            f3 emission;
+            if (hit) emission = surface_emission(sc, resolve_surface(sc, c.inst, c.tri, c.u, c.v));
+            else emission = environment_radiance(sc, dir);
+            const f3 term = mul(mk3(ff.x, ff.y, ff.z), emission);
+            if (TYPE == LUPIN_PATHTRACE_MIS) radiance = add(radiance, scale(term, dd.w));
+            else radiance = add(radiance, divs(term, dd.w));
         }
-        else trace_alpha(geo, sc, lds_stack, mk3(orr.x, orr.y, orr.z), mk3(dm.x, dm.y, dm.z), rng, fp.pc.ray_epsilon, hitrec, hit_tri);
-        alive = shade_path<TYPE>(geo, sc, lds_stack, fp, pb, slot, orr, dm, rng, hitrec, hit_tri);
+
+        const float4 dm = pb.dir_meta[slot];
+        uint32_t meta = __float_as_uint(dm.w);
+        if (!(meta & META_TERMINATED))
+        {
+            alive = true;
+            if (flags) pb.radiance[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+        }
+        else
+        {
+            float4 c4 = pb.color[slot];
+            f3 cr = clamp_radiance(radiance, fp.pc.max_radiance);
+            pb.color[slot] = make_float4(c4.x + cr.x, c4.y + cr.y, c4.z + cr.z, 0.0f);
+            uint32_t sample = (meta >> META_SAMPLE_SHIFT) + 1u;
+            if (sample < fp.spp)
+            {
+                alive = true;
+                uint32_t rng = __float_as_uint(pb.ori_rng[slot].w);
+                uint32_t gx, gy;
+                slot_to_pixel(fp, slot, gx, gy);
+                f3 o, d;
+                camera_ray(fp, gx, gy, rng, o, d);
+                pb.weight[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+                pb.radiance[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                pb.next_hit[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(HIT_MISS));
+                pb.next_tri[slot] = 0u;
+                pb.ori_rng[slot] = make_float4(o.x, o.y, o.z, __uint_as_float(rng));
+                pb.dir_meta[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(META_NEXT_EMISSION | (sample << META_SAMPLE_SHIFT)));
+            }
+        }
     }
     queue_append(alive, slot, pb.queue[(iter + 1) & 1] + (size_t)shard * pb.shard_cap, &pb.counts[(iter + 1) * LP_SHARDS + shard]);
 }
@@ -949,7 +1032,6 @@ struct LupinContext
     unsigned long long *stat_counters = nullptr;   // per shard: [2s] path bounces, [2s+1] paths
     bool timing = false;
     int store_rounding = 0;        // LUPIN_STORE_ROUND_TOWARD_ZERO
-    bool fused_pipeline = false;    // LUPIN_PIPELINE=fused: one trace+shade kernel per bounce instead of two stages
     bool lds_geometry = true;       // LUPIN_LDS_GEOMETRY=0 keeps small scenes in global memory (A/B runs)
     bool persistent_extend = false; // LUPIN_EXTEND=persistent selects the lane-refill kernel (measured slower)
     uint32_t resident_blocks = 1024;
@@ -1020,10 +1102,11 @@ static int ensure_path_buffers(LupinContext *ctx, uint64_t slots, uint32_t itera
         PathBuffers &pb = ctx->pb;
         void **ptrs[] = {(void **)&pb.ori_rng, (void **)&pb.dir_meta, (void **)&pb.weight, (void **)&pb.radiance, (void **)&pb.color,
                          (void **)&pb.hit, (void **)&pb.hit_tri, (void **)&pb.vol0, (void **)&pb.vol1, (void **)&pb.next_hit,
-                         (void **)&pb.next_tri, (void **)&pb.queue[0], (void **)&pb.queue[1]};
-        size_t elem[] = {16, 16, 16, 16, 16, 16, 4, 16, 16, 16, 4, 4, 4};
+                         (void **)&pb.next_tri, (void **)&pb.queue[0], (void **)&pb.queue[1],
+                         (void **)&pb.sh_org, (void **)&pb.sh_d0, (void **)&pb.sh_f0, (void **)&pb.sh_d1, (void **)&pb.sh_f1};
+        size_t elem[] = {16, 16, 16, 16, 16, 16, 4, 16, 16, 16, 4, 4, 4, 16, 16, 16, 16, 16};
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        for (int k = 0; k < 13; k++)
+        for (int k = 0; k < 18; k++)
         {
             if (*ptrs[k]) { hipFree(*ptrs[k]); *ptrs[k] = nullptr; }
             HIP_TRY(hipMalloc(ptrs[k], (size_t)slots * elem[k]));
@@ -1069,19 +1152,6 @@ static void launch_iteration_t(LupinContext *ctx, const LupinScene *scene, const
 {
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     if (ctx->timing) { e0 = get_event(ctx); e1 = get_event(ctx); e2 = get_event(ctx); hipEventRecord(e0, ctx->stream); }
-    if (ctx->fused_pipeline)
-    {
-        hipLaunchKernelGGL((k_bounce<TYPE, LDSGEO>), dim3(blocks), dim3(LP_BLOCK), lds, ctx->stream, scene->dev, fp, ctx->pb, iter, ctx->stat_counters, stack_words);
-        if (ctx->timing)
-        {
-            hipEventRecord(e1, ctx->stream);
-            hipEventRecord(e2, ctx->stream);
-            ctx->ev_extend.push_back({e0, e1});   // the fused kernel is booked as "extend"; "shade" stays ~0
-            ctx->ev_shade.push_back({e1, e2});
-        }
-        ctx->extend_launches++;
-        return;
-    }
     if (ctx->persistent_extend && !LDSGEO)
         hipLaunchKernelGGL(k_extend_persistent<TYPE>, dim3(ctx->resident_blocks), dim3(LP_BLOCK), lds, ctx->stream,
                            scene->dev, fp, ctx->pb, iter, ctx->stat_counters);
@@ -1089,6 +1159,8 @@ static void launch_iteration_t(LupinContext *ctx, const LupinScene *scene, const
         hipLaunchKernelGGL((k_extend<TYPE, LDSGEO>), dim3(blocks), dim3(LP_BLOCK), lds, ctx->stream, scene->dev, fp, ctx->pb, iter, ctx->stat_counters, stack_words);
     if (ctx->timing) hipEventRecord(e1, ctx->stream);
     hipLaunchKernelGGL((k_shade<TYPE, LDSGEO>), dim3(blocks), dim3(LP_BLOCK), lds, ctx->stream, scene->dev, fp, ctx->pb, iter, ctx->stat_counters, stack_words);
+    if (TYPE == LUPIN_PATHTRACE_MIS || TYPE == LUPIN_PATHTRACE_DIRECT)   // shadow rays + path finish (booked with "shade" in the timing)
+        hipLaunchKernelGGL((k_shadow<TYPE, LDSGEO>), dim3(blocks), dim3(LP_BLOCK), lds, ctx->stream, scene->dev, fp, ctx->pb, iter, stack_words);
     if (ctx->timing)
     {
         hipEventRecord(e2, ctx->stream);
@@ -1132,8 +1204,6 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
     hipMemsetAsync(ctx->stat_counters, 0, 2 * LP_SHARDS * sizeof(unsigned long long), ctx->stream);
     const char *ext = getenv("LUPIN_EXTEND");
     ctx->persistent_extend = (ext && strcmp(ext, "persistent") == 0);
-    const char *pl = getenv("LUPIN_PIPELINE");
-    ctx->fused_pipeline = (pl && strcmp(pl, "fused") == 0);
     const char *lg = getenv("LUPIN_LDS_GEOMETRY");
     ctx->lds_geometry = !(lg && strcmp(lg, "0") == 0);
     hipDeviceProp_t prop;
@@ -1155,7 +1225,8 @@ void lupin_hip_destroy_context(LupinContext *ctx)
     hipStreamSynchronize(ctx->stream);
     PathBuffers &pb = ctx->pb;
     void *ptrs[] = {pb.ori_rng, pb.dir_meta, pb.weight, pb.radiance, pb.color, pb.hit, pb.hit_tri, pb.vol0, pb.vol1,
-                    pb.next_hit, pb.next_tri, pb.queue[0], pb.queue[1], pb.counts, ctx->stat_counters};
+                    pb.next_hit, pb.next_tri, pb.queue[0], pb.queue[1], pb.counts, ctx->stat_counters,
+                    pb.sh_org, pb.sh_d0, pb.sh_f0, pb.sh_d1, pb.sh_f1};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &pr : ctx->ev_extend) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto &pr : ctx->ev_shade) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
