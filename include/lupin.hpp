@@ -68,6 +68,7 @@ inline Material default_material()   // renderer.rs:163-185
 }
 
 enum class PathtraceType : uint32_t { Standard = 0, MIS = 1, Naive = 2, Direct = 3 };   // renderer.rs:711-729
+enum class FalsecolorType : uint32_t { Albedo = 0, Normals, NormalsUnsigned, FrontFacing, Emission, Roughness, Metallic, Opacity, MatType, IsDelta, Instance, Tri };   // renderer.rs:843-870
 
 struct BakedPathtraceParams   // renderer.rs:451-468
 {
@@ -302,13 +303,9 @@ inline Scene build_accel_structures_and_upload(const Device &d, const SceneCPU &
     return out;
 }
 
-// lp::pathtrace_scene (renderer.rs:768-842): enqueues one accumulation frame (or one tile) and returns.
-inline void pathtrace_scene(const Device &d, const PathtraceResources &res, const Scene &scene, TextureRef render_target,
-                            PathtraceType type, const PathtraceDesc &desc)
+namespace detail {
+inline void fill_desc(const PathtraceDesc &desc, LupinAccumulationParams &ap, LupinTileParams &tp, LupinPathtraceDesc &c)
 {
-    LupinAccumulationParams ap{};
-    LupinTileParams tp{};
-    LupinPathtraceDesc c{};
     if (desc.accum_params) { ap.prev_frame = desc.accum_params->prev_frame.raw(); ap.accum_counter = desc.accum_params->accum_counter; c.accum_params = &ap; }
     if (desc.tile_params) { tp.tile_size = desc.tile_params->tile_size; tp.tile_idx = desc.tile_params->tile_idx; c.tile_params = &tp; }
     c.camera_params = LupinCameraParams{desc.camera_params.is_orthographic ? 1u : 0u, desc.camera_params.lens, desc.camera_params.film,
@@ -316,7 +313,29 @@ inline void pathtrace_scene(const Device &d, const PathtraceResources &res, cons
     c.camera_transform = desc.camera_transform;
     c.force_software_bvh = desc.force_software_bvh ? 1u : 0u;
     c.advanced = LupinAdvancedParams{desc.advanced.max_radiance, desc.advanced.rng_seed, desc.advanced.ray_epsilon};
+}
+}  // namespace detail
+
+// lp::pathtrace_scene (renderer.rs:768-842): enqueues one accumulation frame (or one tile) and returns.
+inline void pathtrace_scene(const Device &d, const PathtraceResources &res, const Scene &scene, TextureRef render_target,
+                            PathtraceType type, const PathtraceDesc &desc)
+{
+    LupinAccumulationParams ap{};
+    LupinTileParams tp{};
+    LupinPathtraceDesc c{};
+    detail::fill_desc(desc, ap, tp, c);
     check(lupin_hip_pathtrace_scene(d.raw(), res.raw(), scene.raw(), render_target.raw(), (uint32_t)type, &c));
+}
+
+// lp::pathtrace_scene_falsecolor (renderer.rs:872-948)
+inline void pathtrace_scene_falsecolor(const Device &d, const PathtraceResources &res, const Scene &scene, TextureRef render_target,
+                                       FalsecolorType type, const PathtraceDesc &desc)
+{
+    LupinAccumulationParams ap{};
+    LupinTileParams tp{};
+    LupinPathtraceDesc c{};
+    detail::fill_desc(desc, ap, tp, c);
+    check(lupin_hip_pathtrace_scene_falsecolor(d.raw(), res.raw(), scene.raw(), render_target.raw(), (uint32_t)type, &c));
 }
 
 }  // namespace lp

@@ -364,6 +364,20 @@ int lupin_hip_pathtrace_scene(LupinContext *ctx, const LupinPathtraceResources *
                               const LupinScene *scene, LupinTexture *render_target,
                               uint32_t pathtrace_type, const LupinPathtraceDesc *desc);
 
+/* renderer.rs:843-870 FalsecolorType */
+enum LupinFalsecolorType {
+    LUPIN_FALSECOLOR_ALBEDO = 0, LUPIN_FALSECOLOR_NORMALS = 1, LUPIN_FALSECOLOR_NORMALS_UNSIGNED = 2,
+    LUPIN_FALSECOLOR_FRONT_FACING = 3, LUPIN_FALSECOLOR_EMISSION = 4, LUPIN_FALSECOLOR_ROUGHNESS = 5,
+    LUPIN_FALSECOLOR_METALLIC = 6, LUPIN_FALSECOLOR_OPACITY = 7, LUPIN_FALSECOLOR_MAT_TYPE = 8,
+    LUPIN_FALSECOLOR_IS_DELTA = 9, LUPIN_FALSECOLOR_INSTANCE = 10, LUPIN_FALSECOLOR_TRI = 11
+};
+/* lp::pathtrace_scene_falsecolor (renderer.rs:872-948; shader entry pathtrace_falsecolor_main,
+ * pathtracer.wgsl:296-452): G-buffers for denoisers and visual debugging.  Same dispatch / tiling / accumulation
+ * rules as lupin_hip_pathtrace_scene. */
+int lupin_hip_pathtrace_scene_falsecolor(LupinContext *ctx, const LupinPathtraceResources *res,
+                                         const LupinScene *scene, LupinTexture *render_target,
+                                         uint32_t falsecolor_type, const LupinPathtraceDesc *desc);
+
 /* Tile-sharded variant for multi-GPU rendering (extension; the reference renders tiles one
  * sub-dispatch at a time on one device, renderer.rs:807-829): renders, in ONE wavefront launch,
  * every tile t of the frame with t % world == rank (tiles of tile_size*4 pixels, numbered

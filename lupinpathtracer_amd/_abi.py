@@ -159,6 +159,7 @@ SYMBOLS = [
     ("lupin_hip_dbuf_resize", C.c_int, [_P, _U32, _U32]),
     ("lupin_hip_get_num_tiles", _U32, [_U32, _U32, _U32]),
     ("lupin_hip_pathtrace_scene", C.c_int, [_P, _P, _P, _P, _U32, C.POINTER(PathtraceDescC)]),
+    ("lupin_hip_pathtrace_scene_falsecolor", C.c_int, [_P, _P, _P, _P, _U32, C.POINTER(PathtraceDescC)]),
     ("lupin_hip_pathtrace_scene_tiles", C.c_int, [_P, _P, _P, _P, _U32, C.POINTER(PathtraceDescC), _U32, _U32, _U32]),
     ("lupin_hip_stats_reset", C.c_int, [_P, C.c_int]),
     ("lupin_hip_stats_get", C.c_int, [_P, C.POINTER(StatsC)]),

@@ -36,6 +36,21 @@ class PathtraceType(enum.IntEnum):  # renderer.rs:711-729
     Direct = 3
 
 
+class FalsecolorType(enum.IntEnum):  # renderer.rs:843-870
+    Albedo = 0
+    Normals = 1
+    NormalsUnsigned = 2
+    FrontFacing = 3
+    Emission = 4
+    Roughness = 5
+    Metallic = 6
+    Opacity = 7
+    MatType = 8
+    IsDelta = 9
+    Instance = 10
+    Tri = 11
+
+
 class MaterialType(enum.IntEnum):  # renderer.rs:126-139
     Matte = 0
     Glossy = 1
@@ -610,6 +625,17 @@ def pathtrace_scene(ctx, resources, scene, render_target, pathtrace_type, desc):
     c = _desc_to_c(desc, keep)
     check(lib().lupin_hip_pathtrace_scene(ctx.handle, resources.handle, scene.handle, render_target.handle,
                                           int(pathtrace_type), C.byref(c)))
+
+
+def pathtrace_scene_falsecolor(ctx, resources, scene, render_target, falsecolor_type, desc):
+    """lp::pathtrace_scene_falsecolor (renderer.rs:872-948)."""
+    assert render_target.format() == "Rgba16Float"
+    if scene.handle is None:
+        raise LupinError(_abi_code("LUPIN_ERR_NO_DEVICE"), "scene was built without a device context; there is no CPU fallback")
+    keep = []
+    c = _desc_to_c(desc, keep)
+    check(lib().lupin_hip_pathtrace_scene_falsecolor(ctx.handle, resources.handle, scene.handle, render_target.handle,
+                                                     int(falsecolor_type), C.byref(c)))
 
 
 def pathtrace_scene_tiles(ctx, resources, scene, render_target, pathtrace_type, desc, tile_size, rank, world):

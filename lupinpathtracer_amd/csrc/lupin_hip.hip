@@ -940,6 +940,96 @@ __global__ void __launch_bounds__(LP_BLOCK) k_resolve(FrameParams fp, PathBuffer
     out[px + 3] = __float2half_rn(1.0f);
 }
 
+// pathtrace_falsecolor_main (pathtracer.wgsl:296-452): G-buffer style visualisations, one thread per pixel, no bounces.
+__device__ __forceinline__ f3 hash_color(uint32_t id)   // :544-573
+{
+    uint32_t st = id;
+    float c[3];
+    for (int k = 0; k < 3; k++)
+    {
+        st = st * 747796405u + 2891336453u;
+        uint32_t r = ((st >> ((st >> 28u) + 4u)) ^ st) * 277803737u;
+        r = (r >> 22u) ^ r;
+        c[k] = (float)r / 4294967295.0f;
+    }
+    return mk3(c[0], c[1], c[2]);
+}
+
+template <bool LDSGEO>
+__global__ void __launch_bounds__(LP_BLOCK) k_falsecolor(SceneDev sc, FrameParams fp, uint32_t n, const __half *prev, __half *out, uint32_t stack_words)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+    const auto geo = make_geo<LDSGEO>(sc, lds_stack, stack_words);
+    const uint32_t slot = blockIdx.x * LP_BLOCK + threadIdx.x;
+    if (slot >= n) return;
+    uint32_t gx, gy;
+    slot_to_pixel(fp, slot, gx, gy);
+    if (gx >= fp.width || gy >= fp.height) return;
+    const float eps = fp.pc.ray_epsilon;
+    const uint32_t type = fp.pc.falsecolor_type;
+    uint32_t rng = rng_seed_for(gy * fp.width + gx, fp.pc.accum_counter);
+    f3 color = splat(0.0f);
+    for (uint32_t sample = 0; sample < fp.spp; sample++)
+    {
+        f3 o, d;
+        camera_ray(fp, gx, gy, rng, o, d);
+        float4 hitrec;
+        uint32_t hit_tri;
+        if (type <= 6) trace_alpha(geo, sc, lds_stack, o, d, rng, eps, hitrec, hit_tri);
+        else if (type <= 11)
+        {
+            const Closest c = scene_closest(geo, sc, lds_stack, o, d, eps);
+            const bool hit = c.t != LP_F32_MAX;
+            hitrec = make_float4(c.t, c.u, c.v, __uint_as_float(hit ? c.inst : HIT_MISS));
+            hit_tri = c.tri;
+        }
+        else continue;
+        const uint32_t inst = __float_as_uint(hitrec.w);
+        if (inst == HIT_MISS) continue;
+        const Surface s = resolve_surface(sc, inst, hit_tri, hitrec.y, hitrec.z);
+        f3 add_c;
+        switch (type)
+        {
+        case 0: add_c = material_point(sc, s).color; break;
+        case 1: add_c = shading_normal(geo, sc, s); break;
+        case 2: { f3 nn = shading_normal(geo, sc, s); add_c = mk3(nn.x * 0.5f + 0.5f, nn.y * 0.5f + 0.5f, nn.z * 0.5f + 0.5f); break; }
+        case 3:
+        {
+            // hit_backside = det > 0 with det = dot(local dir, cross(v1 - v0, v2 - v0)) of the winning triangle
+            // (bvh_custom.wgsl:106, pathtracer.wgsl:2933-2935); recomputed from the instance-local direction
+            const TriVerts tv = geo.tri(hit_tri);
+            const f3 ld = mk3(d.x * s.in.r0.x + d.y * s.in.r0.y + d.z * s.in.r0.z + 0.0f * s.in.r0.w,
+                              d.x * s.in.r1.x + d.y * s.in.r1.y + d.z * s.in.r1.z + 0.0f * s.in.r1.w,
+                              d.x * s.in.r2.x + d.y * s.in.r2.y + d.z * s.in.r2.z + 0.0f * s.in.r2.w);
+            const float det = dot3(ld, cross3(sub(xyz(tv.v1), xyz(tv.v0)), sub(xyz(tv.v2), xyz(tv.v0))));
+            add_c = splat(det > 0.0f ? 0.0f : 1.0f);
+            break;
+        }
+        case 4: add_c = material_point(sc, s).emission; break;
+        case 5: add_c = splat(material_point(sc, s).roughness); break;
+        case 6: add_c = splat(material_point(sc, s).metallic); break;
+        case 7: add_c = splat(material_point(sc, s).opacity); break;
+        case 8: add_c = hash_color(s.in.mat_idx); break;
+        case 9: add_c = splat(mat_is_delta(material_point(sc, s)) ? 1.0f : 0.0f); break;
+        case 10: add_c = hash_color(inst); break;
+        default: add_c = hash_color(hit_tri - s.mesh.tri_offset); break;
+        }
+        color = add(color, add_c);
+    }
+    const float spp = (float)fp.spp;
+    f3 c = mk3(maxf(color.x / spp, 0.0f), maxf(color.y / spp, 0.0f), maxf(color.z / spp, 0.0f));
+    const size_t px = ((size_t)gy * fp.width + gx) * 4;
+    if (fp.pc.accum_counter != 0)
+    {
+        float w = 1.0f / (float)fp.pc.accum_counter;
+        f3 pc = mk3(__half2float(prev[px + 0]), __half2float(prev[px + 1]), __half2float(prev[px + 2]));
+        c = mk3(maxf(pc.x * (1.0f - w) + c.x * w, 0.0f), maxf(pc.y * (1.0f - w) + c.y * w, 0.0f), maxf(pc.z * (1.0f - w) + c.z * w, 0.0f));
+    }
+    if (fp.store_rne) { out[px + 0] = __float2half_rn(c.x); out[px + 1] = __float2half_rn(c.y); out[px + 2] = __float2half_rn(c.z); }
+    else { out[px + 0] = __float2half_rz(c.x); out[px + 1] = __float2half_rz(c.y); out[px + 2] = __float2half_rz(c.z); }
+    out[px + 3] = __float2half_rn(1.0f);
+}
+
 // standalone closest-hit probe (bvh_custom.wgsl:7-110)
 __global__ void __launch_bounds__(LP_BLOCK) k_trace(SceneDev sc, uint32_t n, const float *ori, const float *dir, float eps,
                                                     uint32_t *out_hit, float *out_dst, float *out_uv, uint32_t *out_inst, uint32_t *out_tri)
@@ -1687,10 +1777,11 @@ int lupin_hip_dbuf_resize(LupinDoubleBufferedTexture *t, uint32_t width, uint32_
 
 static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res, const LupinScene *scene,
                           LupinTexture *render_target, uint32_t pathtrace_type, const LupinPathtraceDesc *desc,
-                          bool tile_set, uint32_t set_tile_size, uint32_t rank, uint32_t world)
+                          bool tile_set, uint32_t set_tile_size, uint32_t rank, uint32_t world, int falsecolor_type = -1)
 {
     if (!ctx || !res || !scene || !render_target || !desc) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
-    if (pathtrace_type > LUPIN_PATHTRACE_DIRECT) return fail(LUPIN_ERR_INVALID_ARGUMENT, "unknown pathtrace_type");
+    if (falsecolor_type < 0 && pathtrace_type > LUPIN_PATHTRACE_DIRECT) return fail(LUPIN_ERR_INVALID_ARGUMENT, "unknown pathtrace_type");
+    if (falsecolor_type > 11) return fail(LUPIN_ERR_INVALID_ARGUMENT, "unknown falsecolor_type");
     if (!scene->has_sw_bvh) return fail(LUPIN_ERR_NO_SW_BVH, "no software BVH was built for this scene");   // renderer.rs:774-777
     const uint32_t W = render_target->width, H = render_target->height;
     const LupinTexture *prev = desc->accum_params ? desc->accum_params->prev_frame : nullptr;
@@ -1713,7 +1804,8 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
     if (scene->envs_empty) pc.flags |= LUPIN_FLAG_ENVS_EMPTY;
     if (scene->lights_empty) pc.flags |= LUPIN_FLAG_LIGHTS_EMPTY;
     if (scene->instances_empty) pc.flags |= LUPIN_FLAG_INSTANCES_EMPTY;
-    pc.pathtrace_type = pathtrace_type;
+    pc.pathtrace_type = falsecolor_type < 0 ? pathtrace_type : 0u;   // get_push_constants leaves the other selector at 0
+    pc.falsecolor_type = falsecolor_type < 0 ? 0u : (uint32_t)falsecolor_type;
     pc.accum_counter = desc->accum_params ? desc->accum_params->accum_counter : 0u;
     pc.max_radiance = desc->advanced.max_radiance;
     pc.rng_seed = desc->advanced.rng_seed;
@@ -1764,6 +1856,20 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
     if (n64 > 0x7FFFFFFFull) return fail(LUPIN_ERR_INVALID_ARGUMENT, "dispatch too large");
     const uint32_t n = (uint32_t)n64;
 
+    if (falsecolor_type >= 0)
+    {
+        const uint32_t fblocks = (n + LP_BLOCK - 1) / LP_BLOCK;
+        const uint32_t fstack_words = scene->stack_entries * LP_BLOCK;
+        const bool flds = scene->dev.geo_blob_words && ctx->lds_geometry;
+        const size_t flds_bytes = (size_t)fstack_words * sizeof(uint32_t) + (flds ? (size_t)scene->dev.geo_blob_words * 16 : 0);
+        if (flds_bytes > 160 * 1024) return fail(LUPIN_ERR_INVALID_ARGUMENT, "BVH too deep for the LDS traversal stack");
+        const __half *pv = prev ? prev->data : (const __half *)nullptr;
+        if (flds) hipLaunchKernelGGL(k_falsecolor<true>, dim3(fblocks), dim3(LP_BLOCK), flds_bytes, ctx->stream, scene->dev, fp, n, pv, render_target->data, fstack_words);
+        else hipLaunchKernelGGL(k_falsecolor<false>, dim3(fblocks), dim3(LP_BLOCK), flds_bytes, ctx->stream, scene->dev, fp, n, pv, render_target->data, fstack_words);
+        HIP_TRY(hipGetLastError());
+        return LUPIN_OK;
+    }
+
     const uint32_t iterations = fp.spp * (fp.max_bounces + 1);
     int rc = ensure_path_buffers(ctx, n, iterations);
     if (rc != LUPIN_OK) return rc;
@@ -1804,6 +1910,13 @@ int lupin_hip_pathtrace_scene(LupinContext *ctx, const LupinPathtraceResources *
                               LupinTexture *render_target, uint32_t pathtrace_type, const LupinPathtraceDesc *desc)
 {
     return pathtrace_impl(ctx, res, scene, render_target, pathtrace_type, desc, false, 0, 0, 1);
+}
+
+int lupin_hip_pathtrace_scene_falsecolor(LupinContext *ctx, const LupinPathtraceResources *res, const LupinScene *scene,
+                                         LupinTexture *render_target, uint32_t falsecolor_type, const LupinPathtraceDesc *desc)
+{
+    if (falsecolor_type > 11) return fail(LUPIN_ERR_INVALID_ARGUMENT, "unknown falsecolor_type");
+    return pathtrace_impl(ctx, res, scene, render_target, 0, desc, false, 0, 0, 1, (int)falsecolor_type);
 }
 
 int lupin_hip_pathtrace_scene_tiles(LupinContext *ctx, const LupinPathtraceResources *res, const LupinScene *scene,

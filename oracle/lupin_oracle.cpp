@@ -2054,6 +2054,74 @@ struct Inv
         return radiance;
     }
 
+    // hash_color (:544-573): three PCG draws from a local state seeded with the id
+    static vec3f hash_color(uint32_t id)
+    {
+        uint32_t local_state = id;
+        float c[3];
+        for (int k = 0; k < 3; k++)
+        {
+            local_state = local_state * 747796405u + 2891336453u;
+            uint32_t result = ((local_state >> ((local_state >> 28u) + 4u)) ^ local_state) * 277803737u;
+            result = (result >> 22u) ^ result;
+            c[k] = (float)result / 4294967295.0f;
+        }
+        return {c[0], c[1], c[2]};
+    }
+
+    // ---- pathtrace_falsecolor_main (:296-452), one invocation ----
+    bool pathtrace_falsecolor_main(uint32_t gx, uint32_t gy, uint32_t dim_x, uint32_t dim_y, const uint16_t *prev_frame, float out_rgb[3])
+    {
+        init_rng(gy * dim_x + gx);
+        vec3f color = v3(0.0f);
+        for (uint32_t sample = 0; sample < SAMPLES_PER_PIXEL; sample++)
+        {
+            vec2f ro = random_vec2f();
+            vec2f pixel_offset = {ro.x - 0.5f, ro.y - 0.5f};
+            Ray camera_ray = compute_camera_ray(gx, gy, dim_x, dim_y, pixel_offset);
+            const uint32_t t = constants.falsecolor_type;
+            if (t <= 6)   // ALBEDO .. METALLIC use the alpha-skipping query
+            {
+                HitInfo hit = ray_skip_alpha_stochastically(camera_ray);
+                if (hit.hit)
+                {
+                    if (t == 0) color += get_material_point(hit).color;
+                    else if (t == 1) color += compute_shading_normal(hit);
+                    else if (t == 2) color += compute_shading_normal(hit) * 0.5f + 0.5f;
+                    else if (t == 3) color += v3(hit.hit_backside ? 0.0f : 1.0f);
+                    else if (t == 4) color += get_material_point(hit).emission;
+                    else if (t == 5) color += v3(get_material_point(hit).roughness);
+                    else color += v3(get_material_point(hit).metallic);
+                }
+            }
+            else if (t <= 11)   // OPACITY .. TRI use the plain closest hit
+            {
+                HitInfo hit = ray_scene_intersection(camera_ray);
+                if (hit.hit)
+                {
+                    if (t == 7) color += v3(get_material_point(hit).opacity);
+                    else if (t == 8) color += hash_color(s->instances[hit.instance_idx].mat_idx);
+                    else if (t == 9) color += v3(is_mat_delta(get_material_point(hit)) ? 1.0f : 0.0f);
+                    else if (t == 10) color += hash_color(hit.instance_idx);
+                    else color += hash_color(hit.tri_idx);
+                }
+            }
+        }
+        color = color / (float)SAMPLES_PER_PIXEL;
+        color = max3(color, v3(0.0f));
+        bool in_bounds = gx < dim_x && gy < dim_y;
+        if (constants.accum_counter != 0 && in_bounds)
+        {
+            float weight = 1.0f / (float)constants.accum_counter;
+            const uint16_t *p = prev_frame + ((size_t)gy * dim_x + gx) * 4;
+            vec3f prev_color = {half_to_float(p[0]), half_to_float(p[1]), half_to_float(p[2])};
+            color = prev_color * (1.0f - weight) + color * weight;
+            color = max3(color, v3(0.0f));
+        }
+        out_rgb[0] = color.x; out_rgb[1] = color.y; out_rgb[2] = color.z;
+        return in_bounds;
+    }
+
     // ---- pathtrace_main (:220-292), one invocation ----
     // gx, gy already include constants.id_offset. Returns false when the texel is out of bounds
     // (the invocation still runs in the reference; its result is discarded).
@@ -2128,12 +2196,13 @@ struct OracleCounters
 // prev_frame / out_rgba16f: W*H*4 half floats (row 0 = top); prev_frame may be NULL when
 // accum_counter == 0.  out_rgb_f32 (optional, W*H*3) receives the unquantised colour.
 // store_rounding: 0 = toward zero (what the reference's goldens show), 1 = nearest even.
+// falsecolor != 0 runs pathtrace_falsecolor_main (pathtracer.wgsl:296-452) with constants->falsecolor_type instead.
 // Texels outside the dispatch are left untouched.  Returns 0 on success.
 int oracle_pathtrace(const LupinSceneDesc *scene, const LupinPushConstants *constants,
                      uint32_t max_bounces, uint32_t samples_per_pixel,
                      uint32_t width, uint32_t height, uint32_t groups_x, uint32_t groups_y,
                      const uint16_t *prev_frame, uint16_t *out_rgba16f, float *out_rgb_f32,
-                     OracleCounters *counters, int num_threads, int store_rounding)
+                     OracleCounters *counters, int num_threads, int store_rounding, int falsecolor)
 {
     auto to_half = [store_rounding](float f) { return store_rounding == 1 ? float_to_half_rne(f) : float_to_half_rtz(f); };
     if (!scene || !constants || !out_rgba16f) return -1;
@@ -2158,7 +2227,8 @@ int oracle_pathtrace(const LupinSceneDesc *scene, const LupinPushConstants *cons
                 inv.s = scene; inv.constants = *constants;
                 inv.MAX_BOUNCES = max_bounces; inv.SAMPLES_PER_PIXEL = samples_per_pixel;
                 float rgb[3];
-                inv.pathtrace_main(gx, gy, width, height, prev_frame, rgb);
+                if (falsecolor) inv.pathtrace_falsecolor_main(gx, gy, width, height, prev_frame, rgb);
+                else inv.pathtrace_main(gx, gy, width, height, prev_frame, rgb);
                 size_t o = (size_t)gy * width + gx;
                 out_rgba16f[o * 4 + 0] = to_half(rgb[0]);
                 out_rgba16f[o * 4 + 1] = to_half(rgb[1]);

@@ -39,7 +39,7 @@ def lib():
         h.oracle_pathtrace.restype = C.c_int
         h.oracle_pathtrace.argtypes = [C.POINTER(_abi.SceneDesc), C.POINTER(_abi.PushConstants), C.c_uint32, C.c_uint32,
                                        C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
-                                       C.POINTER(OracleCounters), C.c_int, C.c_int]
+                                       C.POINTER(OracleCounters), C.c_int, C.c_int, C.c_int]
         h.oracle_trace_rays.restype = C.c_int
         h.oracle_trace_rays.argtypes = [C.POINTER(_abi.SceneDesc), C.c_uint32, C.c_void_p, C.c_void_p, C.c_float, C.c_uint32,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -99,10 +99,12 @@ def dispatch_extent(width, height, tile_params=None):
 
 def pathtrace(scene, width, height, camera_params, camera_transform, max_bounces=8, samples_per_pixel=5, pathtrace_type=0,
               accum_counter=0, prev_frame=None, advanced=None, tile_params=None, out=None, num_threads=0, want_f32=False,
-              store_rounding=0):
+              store_rounding=0, falsecolor_type=None):
     """One pathtrace_scene call on the CPU.  Returns (rgba16f (H,W,4) float16, counters dict[, rgb f32])."""
     (ox, oy), gx, gy = dispatch_extent(width, height, tile_params)
     pc = push_constants(scene, camera_params, camera_transform, pathtrace_type, accum_counter, advanced, (ox, oy))
+    if falsecolor_type is not None:
+        pc.falsecolor_type = int(falsecolor_type)
     if out is None:
         out = np.zeros((height, width, 4), np.float16)
     f32 = np.zeros((height, width, 3), np.float32) if want_f32 else None
@@ -112,7 +114,8 @@ def pathtrace(scene, width, height, camera_params, camera_transform, max_bounces
         assert prev.shape == (height, width, 4)
     cnt = OracleCounters()
     rc = lib().oracle_pathtrace(C.byref(scene.desc), C.byref(pc), max_bounces, samples_per_pixel, width, height, gx, gy,
-                                _abi.ptr(prev), _abi.ptr(out), _abi.ptr(f32), C.byref(cnt), num_threads, store_rounding)
+                                _abi.ptr(prev), _abi.ptr(out), _abi.ptr(f32), C.byref(cnt), num_threads, store_rounding,
+                                0 if falsecolor_type is None else 1)
     if rc != 0:
         raise RuntimeError("oracle_pathtrace failed")
     counters = {}

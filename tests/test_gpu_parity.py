@@ -224,3 +224,42 @@ def test_gpu_vs_reference_golden_renders(gpu_ctx, name, cam_i):
     rel_rmse = float(np.sqrt(((a - b) ** 2).mean()) / g.mean())
     print(f"golden {name} cam{cam_i}: mean ratio {mine.mean() / g.mean():.4f}, block rel-rmse {rel_rmse:.4f}")
     assert rel_rmse < 0.05, rel_rmse
+
+
+@pytest.mark.parametrize("name,cam_i", [("cornellbox_builtin", 0), ("features1", 1), ("materials4", 2)])
+def test_falsecolor_entry_point(gpu_ctx, name, cam_i):
+    """lp::pathtrace_scene_falsecolor (renderer.rs:872-948, pathtracer.wgsl:296-452): all 12 FalsecolorType views,
+    two accumulation frames, against the oracle; plus one tiled call."""
+    from oracle import oracle
+    scene, cams = util.load_scene(name, gpu_ctx)
+    cam = cams[cam_i]
+    W = 128
+    H = max(4, int(W / cam.params.aspect)) // 4 * 4
+    res = api.build_pathtrace_resources(gpu_ctx, api.BakedPathtraceParams(max_bounces=8, samples_per_pixel=3))
+    for ftype in api.FalsecolorType:
+        out = api.DoubleBufferedTexture(gpu_ctx, W, H)
+        prev = np.zeros((H, W, 4), np.float16)
+        for k in range(2):
+            desc = api.PathtraceDesc(accum_params=api.AccumulationParams(out.back(), k), camera_params=cam.params, camera_transform=cam.transform)
+            api.pathtrace_scene_falsecolor(gpu_ctx, res, scene, out.front(), ftype, desc)
+            ref, _ = oracle.pathtrace(scene, W, H, cam.params, cam.transform, 8, 3, accum_counter=k, prev_frame=prev, falsecolor_type=ftype)
+            prev = ref
+            out.flip()
+        out.flip()
+        got = out.front().download()
+        compare(got, ref, f"falsecolor {ftype.name} {name}")
+        if ftype in (api.FalsecolorType.Normals,):
+            nrm = got[..., :3].astype(np.float32)
+            hit = np.abs(nrm).sum(axis=2) > 0
+            assert hit.any()
+    # tiled
+    tex = api.Texture(gpu_ctx, W, H)
+    ref = np.zeros((H, W, 4), np.float16)
+    for t in range(api.get_num_tiles(4, W, H)):
+        api.pathtrace_scene_falsecolor(gpu_ctx, res, scene, tex, api.FalsecolorType.Instance,
+                                       api.PathtraceDesc(tile_params=api.TileParams(4, t), camera_params=cam.params, camera_transform=cam.transform))
+        oracle.pathtrace(scene, W, H, cam.params, cam.transform, 8, 3, tile_params=api.TileParams(4, t), out=ref,
+                         falsecolor_type=api.FalsecolorType.Instance)
+    assert util.f16_words_differ(tex.download(), ref) == 0
+    with pytest.raises(api.LupinError):
+        api.pathtrace_scene_falsecolor(gpu_ctx, res, scene, tex, 12, api.PathtraceDesc())

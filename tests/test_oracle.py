@@ -165,3 +165,29 @@ def test_empty_scene_renders_black(built):
     img, cnt = oracle.pathtrace(scene, 8, 8, api.CameraParams(), api.identity_mat3x4(), 8, 2)
     assert np.all(img[..., :3] == 0) and np.all(img[..., 3] == 1)
     assert cnt["closest_hit_queries"] == 0
+
+
+def test_falsecolor_oracle_sanity(built):
+    """pathtrace_falsecolor_main restated (pathtracer.wgsl:296-452): closed-form checks on the Cornell box."""
+    scene, cams = util.load_scene("cornellbox_builtin")
+    cam = cams[0]
+    W = H = 48
+    def view(t):
+        img, _ = oracle.pathtrace(scene, W, H, cam.params, cam.transform, 8, 4, falsecolor_type=t, store_rounding=1)
+        return img.astype(np.float32)
+    albedo = view(api.FalsecolorType.Albedo)[..., :3]
+    # left wall is red (0.63, 0.065, 0.05), right wall green (0.14, 0.45, 0.091): loader.rs:24-33
+    assert np.allclose(albedo[H // 2, 1], (0.63, 0.065, 0.05), atol=2e-3)
+    assert np.allclose(albedo[H // 2, W - 2], (0.14, 0.45, 0.091), atol=2e-3)
+    normals = view(api.FalsecolorType.Normals)[..., :3]
+    ln = np.linalg.norm(normals, axis=2)
+    assert np.all((ln < 1.01)) and (ln > 0.99).mean() > 0.5      # single-surface pixels carry unit normals
+    unsigned = view(api.FalsecolorType.NormalsUnsigned)[..., :3]
+    assert unsigned.min() >= 0.0 and unsigned.max() <= 1.0
+    emission = view(api.FalsecolorType.Emission)[..., :3]
+    assert emission.max() == 17.0 and (emission.sum(axis=2) > 0).mean() < 0.1
+    for t in (api.FalsecolorType.Opacity,):
+        assert view(t)[..., :3].max() == 1.0
+    assert view(api.FalsecolorType.IsDelta)[..., :3].max() == 0.0     # the Cornell box is all matte
+    inst = view(api.FalsecolorType.Instance)[..., :3]
+    assert len(np.unique(inst.reshape(-1, 3).round(3), axis=0)) >= 6
