@@ -1112,14 +1112,30 @@ static thread_local std::string g_last_error;
 static int fail(int code, const std::string &msg) { g_last_error = msg; return code; }
 #define HIP_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return fail(LUPIN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } while (0)
 
-struct LupinContext
+#define LP_MAX_LANES 4
+// "Lanes" (stream + path buffers + counters) let consecutive pathtrace_scene calls overlap: the wavefront of
+// frame k+1 starts while the thin tail of frame k is still draining.  Frames only meet at k_resolve (frame k+1 blends
+// with frame k's output), which waits on the previous call's completion event.
+struct Lane
 {
-    int device = 0;
     hipStream_t stream = nullptr;
     PathBuffers pb{};
     uint64_t capacity = 0;          // slots the path buffers hold
     uint32_t counts_capacity = 0;
     unsigned long long *stat_counters = nullptr;   // per shard: [2s] path bounces, [2s+1] paths
+    hipEvent_t done = nullptr;      // recorded after the last kernel of the lane's latest call
+    bool used = false;
+};
+
+struct LupinContext
+{
+    int device = 0;
+    hipStream_t stream = nullptr;   // primary stream (= lanes[0].stream): every non-pathtrace operation runs here
+    Lane lanes[LP_MAX_LANES];
+    int num_lanes = 3;              // LUPIN_LANES=1..4 (LUPIN_OVERLAP=0 == 1 lane)
+    uint64_t call_index = 0;
+    int last_lane = -1;
+    hipEvent_t marker = nullptr;
     bool timing = false;
     int store_rounding = 0;        // LUPIN_STORE_ROUND_TOWARD_ZERO
     bool lds_geometry = true;       // LUPIN_LDS_GEOMETRY=0 keeps small scenes in global memory (A/B runs)
@@ -1182,8 +1198,9 @@ static hipEvent_t get_event(LupinContext *ctx)
     return e;
 }
 
-static int ensure_path_buffers(LupinContext *ctx, uint64_t slots, uint32_t iterations)
+static int ensure_path_buffers(LupinContext *ctx0, Lane *ctx, uint64_t slots, uint32_t iterations)
 {
+    (void)ctx0;
     // shard segments are whole blocks: round the queue length up to LP_SHARDS * LP_BLOCK
     const uint64_t per_round = (uint64_t)LP_SHARDS * LP_BLOCK;
     slots = (slots + per_round - 1) / per_round * per_round;
@@ -1238,22 +1255,23 @@ static uint32_t blas_depth(const LupinBvhNode *nodes, uint32_t count)
 }
 
 template <int TYPE, bool LDSGEO>
-static void launch_iteration_t(LupinContext *ctx, const LupinScene *scene, const FrameParams &fp, uint32_t blocks, size_t lds, uint32_t stack_words, uint32_t iter)
+static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *scene, const FrameParams &fp, uint32_t blocks, size_t lds, uint32_t stack_words, uint32_t iter)
 {
+    hipStream_t st = ln->stream;
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-    if (ctx->timing) { e0 = get_event(ctx); e1 = get_event(ctx); e2 = get_event(ctx); hipEventRecord(e0, ctx->stream); }
+    if (ctx->timing) { e0 = get_event(ctx); e1 = get_event(ctx); e2 = get_event(ctx); hipEventRecord(e0, st); }
     if (ctx->persistent_extend && !LDSGEO)
-        hipLaunchKernelGGL(k_extend_persistent<TYPE>, dim3(ctx->resident_blocks), dim3(LP_BLOCK), lds, ctx->stream,
-                           scene->dev, fp, ctx->pb, iter, ctx->stat_counters);
+        hipLaunchKernelGGL(k_extend_persistent<TYPE>, dim3(ctx->resident_blocks), dim3(LP_BLOCK), lds, st,
+                           scene->dev, fp, ln->pb, iter, ln->stat_counters);
     else
-        hipLaunchKernelGGL((k_extend<TYPE, LDSGEO>), dim3(blocks), dim3(LP_BLOCK), lds, ctx->stream, scene->dev, fp, ctx->pb, iter, ctx->stat_counters, stack_words);
-    if (ctx->timing) hipEventRecord(e1, ctx->stream);
-    hipLaunchKernelGGL((k_shade<TYPE, LDSGEO>), dim3(blocks), dim3(LP_BLOCK), lds, ctx->stream, scene->dev, fp, ctx->pb, iter, ctx->stat_counters, stack_words);
+        hipLaunchKernelGGL((k_extend<TYPE, LDSGEO>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
+    if (ctx->timing) hipEventRecord(e1, st);
+    hipLaunchKernelGGL((k_shade<TYPE, LDSGEO>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
     if (TYPE == LUPIN_PATHTRACE_MIS || TYPE == LUPIN_PATHTRACE_DIRECT)   // shadow rays + path finish (booked with "shade" in the timing)
-        hipLaunchKernelGGL((k_shadow<TYPE, LDSGEO>), dim3(blocks), dim3(LP_BLOCK), lds, ctx->stream, scene->dev, fp, ctx->pb, iter, stack_words);
+        hipLaunchKernelGGL((k_shadow<TYPE, LDSGEO>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, stack_words);
     if (ctx->timing)
     {
-        hipEventRecord(e2, ctx->stream);
+        hipEventRecord(e2, st);
         ctx->ev_extend.push_back({e0, e1});
         ctx->ev_shade.push_back({e1, e2});
     }
@@ -1261,10 +1279,24 @@ static void launch_iteration_t(LupinContext *ctx, const LupinScene *scene, const
 }
 
 template <int TYPE>
-static void launch_iteration(LupinContext *ctx, const LupinScene *scene, const FrameParams &fp, uint32_t blocks, size_t lds, uint32_t stack_words, uint32_t iter)
+static void launch_iteration(LupinContext *ctx, Lane *ln, const LupinScene *scene, const FrameParams &fp, uint32_t blocks, size_t lds, uint32_t stack_words, uint32_t iter)
 {
-    if (scene->dev.geo_blob_words && ctx->lds_geometry) launch_iteration_t<TYPE, true>(ctx, scene, fp, blocks, lds, stack_words, iter);
-    else launch_iteration_t<TYPE, false>(ctx, scene, fp, blocks, lds, stack_words, iter);
+    if (scene->dev.geo_blob_words && ctx->lds_geometry) launch_iteration_t<TYPE, true>(ctx, ln, scene, fp, blocks, lds, stack_words, iter);
+    else launch_iteration_t<TYPE, false>(ctx, ln, scene, fp, blocks, lds, stack_words, iter);
+}
+
+// Orders the primary stream after everything the second lane has been asked to do (textures, counters).
+// The resolves form a chain (each waits for the previous call's), so the latest call's event covers all lanes' texture writes.
+static void join_primary(LupinContext *ctx)
+{
+    if (ctx->last_lane > 0) hipStreamWaitEvent(ctx->stream, ctx->lanes[ctx->last_lane].done, 0);
+}
+static hipError_t sync_all(LupinContext *ctx)
+{
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < LP_MAX_LANES && e == hipSuccess; k++)
+        if (ctx->lanes[k].stream) e = hipStreamSynchronize(ctx->lanes[k].stream);
+    return e;
 }
 
 extern "C" {
@@ -1287,11 +1319,22 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
     HIP_TRY(hipSetDevice(device_ordinal));
     LupinContext *ctx = new LupinContext();
     ctx->device = device_ordinal;
-    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { delete ctx; return fail(LUPIN_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
-    e = hipMalloc((void **)&ctx->stat_counters, 2 * LP_SHARDS * sizeof(unsigned long long));
-    if (e != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return fail(LUPIN_ERR_HIP, "hipMalloc(stat counters)"); }
-    hipMemsetAsync(ctx->stat_counters, 0, 2 * LP_SHARDS * sizeof(unsigned long long), ctx->stream);
+    hipError_t e = hipSuccess;
+    const char *ov = getenv("LUPIN_OVERLAP");
+    const char *nl = getenv("LUPIN_LANES");
+    if (nl) ctx->num_lanes = std::min(LP_MAX_LANES, std::max(1, atoi(nl)));
+    if (ov && strcmp(ov, "0") == 0) ctx->num_lanes = 1;
+    for (int k = 0; k < ctx->num_lanes && e == hipSuccess; k++)
+    {
+        Lane &ln = ctx->lanes[k];
+        e = hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ln.done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipMalloc((void **)&ln.stat_counters, 2 * LP_SHARDS * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMemsetAsync(ln.stat_counters, 0, 2 * LP_SHARDS * sizeof(unsigned long long), ln.stream);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->marker, hipEventDisableTiming);
+    if (e != hipSuccess) { delete ctx; return fail(LUPIN_ERR_HIP, std::string("context setup: ") + hipGetErrorString(e)); }
+    ctx->stream = ctx->lanes[0].stream;
     const char *ext = getenv("LUPIN_EXTEND");
     ctx->persistent_extend = (ext && strcmp(ext, "persistent") == 0);
     const char *lg = getenv("LUPIN_LDS_GEOMETRY");
@@ -1312,17 +1355,22 @@ void lupin_hip_destroy_context(LupinContext *ctx)
 {
     if (!ctx) return;
     hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
-    PathBuffers &pb = ctx->pb;
-    void *ptrs[] = {pb.ori_rng, pb.dir_meta, pb.weight, pb.radiance, pb.color, pb.hit, pb.hit_tri, pb.vol0, pb.vol1,
-                    pb.next_hit, pb.next_tri, pb.queue[0], pb.queue[1], pb.counts, ctx->stat_counters,
-                    pb.sh_org, pb.sh_d0, pb.sh_f0, pb.sh_d1, pb.sh_f1};
-    for (void *p : ptrs) if (p) hipFree(p);
+    sync_all(ctx);
+    for (int k = 0; k < LP_MAX_LANES; k++)
+    {
+        PathBuffers &pb = ctx->lanes[k].pb;
+        void *ptrs[] = {pb.ori_rng, pb.dir_meta, pb.weight, pb.radiance, pb.color, pb.hit, pb.hit_tri, pb.vol0, pb.vol1,
+                        pb.next_hit, pb.next_tri, pb.queue[0], pb.queue[1], pb.counts, ctx->lanes[k].stat_counters,
+                        pb.sh_org, pb.sh_d0, pb.sh_f0, pb.sh_d1, pb.sh_f1};
+        for (void *p : ptrs) if (p) hipFree(p);
+        if (ctx->lanes[k].done) hipEventDestroy(ctx->lanes[k].done);
+    }
+    if (ctx->marker) hipEventDestroy(ctx->marker);
     for (auto &pr : ctx->ev_extend) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto &pr : ctx->ev_shade) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto &pr : ctx->ev_total) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto e : ctx->ev_pool) hipEventDestroy(e);
-    hipStreamDestroy(ctx->stream);
+    for (int k = 0; k < LP_MAX_LANES; k++) if (ctx->lanes[k].stream) hipStreamDestroy(ctx->lanes[k].stream);
     delete ctx;
 }
 
@@ -1330,7 +1378,7 @@ int lupin_hip_sync(LupinContext *ctx)
 {
     if (!ctx) return fail(LUPIN_ERR_INVALID_ARGUMENT, "ctx is null");
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(sync_all(ctx));
     return LUPIN_OK;
 }
 
@@ -1681,7 +1729,7 @@ void lupin_hip_scene_destroy(LupinScene *scene)
 {
     if (!scene) return;
     hipSetDevice(scene->ctx->device);
-    hipStreamSynchronize(scene->ctx->stream);
+    sync_all(scene->ctx);
     for (void *p : scene->allocations) hipFree(p);
     delete scene;
 }
@@ -1705,7 +1753,7 @@ void lupin_hip_texture_destroy(LupinTexture *tex)
 {
     if (!tex) return;
     hipSetDevice(tex->ctx->device);
-    hipStreamSynchronize(tex->ctx->stream);
+    sync_all(tex->ctx);
     hipFree(tex->data);
     delete tex;
 }
@@ -1717,6 +1765,7 @@ int lupin_hip_texture_upload_rgba16f(LupinTexture *tex, const uint16_t *pixels)
 {
     if (!tex || !pixels) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
     HIP_TRY(hipSetDevice(tex->ctx->device));
+    join_primary(tex->ctx);
     HIP_TRY(hipMemcpyAsync(tex->data, pixels, (size_t)tex->width * tex->height * 8, hipMemcpyHostToDevice, tex->ctx->stream));
     HIP_TRY(hipStreamSynchronize(tex->ctx->stream));
     return LUPIN_OK;
@@ -1725,6 +1774,7 @@ int lupin_hip_texture_download_rgba16f(const LupinTexture *tex, uint16_t *out_pi
 {
     if (!tex || !out_pixels) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
     HIP_TRY(hipSetDevice(tex->ctx->device));
+    join_primary(tex->ctx);
     HIP_TRY(hipMemcpyAsync(out_pixels, tex->data, (size_t)tex->width * tex->height * 8, hipMemcpyDeviceToHost, tex->ctx->stream));
     HIP_TRY(hipStreamSynchronize(tex->ctx->stream));
     return LUPIN_OK;
@@ -1755,6 +1805,7 @@ int lupin_hip_dbuf_copy_front_to_back(LupinDoubleBufferedTexture *t)
     if (!t) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
     LupinTexture *f = t->tex[t->front_idx], *b = t->tex[t->back_idx];
     HIP_TRY(hipSetDevice(t->ctx->device));
+    join_primary(t->ctx);
     HIP_TRY(hipMemcpyAsync(b->data, f->data, (size_t)f->width * f->height * 8, hipMemcpyDeviceToDevice, t->ctx->stream));
     return LUPIN_OK;
 }
@@ -1864,44 +1915,64 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
         const size_t flds_bytes = (size_t)fstack_words * sizeof(uint32_t) + (flds ? (size_t)scene->dev.geo_blob_words * 16 : 0);
         if (flds_bytes > 160 * 1024) return fail(LUPIN_ERR_INVALID_ARGUMENT, "BVH too deep for the LDS traversal stack");
         const __half *pv = prev ? prev->data : (const __half *)nullptr;
+        join_primary(ctx);
         if (flds) hipLaunchKernelGGL(k_falsecolor<true>, dim3(fblocks), dim3(LP_BLOCK), flds_bytes, ctx->stream, scene->dev, fp, n, pv, render_target->data, fstack_words);
         else hipLaunchKernelGGL(k_falsecolor<false>, dim3(fblocks), dim3(LP_BLOCK), flds_bytes, ctx->stream, scene->dev, fp, n, pv, render_target->data, fstack_words);
         HIP_TRY(hipGetLastError());
         return LUPIN_OK;
     }
 
+    // Lane choice: consecutive calls alternate so that their wavefronts overlap; per-kernel timing needs them serial.
+    const int w = ctx->timing ? 0 : (int)(ctx->call_index % (uint64_t)ctx->num_lanes);
+    ctx->call_index++;
+    Lane *ln = &ctx->lanes[w];
+    hipStream_t st = ln->stream;
+
     const uint32_t iterations = fp.spp * (fp.max_bounces + 1);
-    int rc = ensure_path_buffers(ctx, n, iterations);
+    int rc = ensure_path_buffers(ctx, ln, n, iterations);
     if (rc != LUPIN_OK) return rc;
 
     // grid: every shard gets the same number of blocks, block b serves shard b % LP_SHARDS
     const uint32_t blocks_needed = (n + LP_BLOCK - 1) / LP_BLOCK;
     const uint32_t blocks_per_shard = (blocks_needed + LP_SHARDS - 1) / LP_SHARDS;
     const uint32_t blocks = blocks_per_shard * LP_SHARDS;
-    ctx->pb.shard_cap = blocks_per_shard * LP_BLOCK;
+    ln->pb.shard_cap = blocks_per_shard * LP_BLOCK;
     const uint32_t stack_words = scene->stack_entries * LP_BLOCK;
     const bool lds_geo = scene->dev.geo_blob_words && ctx->lds_geometry;
     const size_t lds = (size_t)stack_words * sizeof(uint32_t) + (lds_geo ? (size_t)scene->dev.geo_blob_words * 16 : 0);
     if (lds > 160 * 1024) return fail(LUPIN_ERR_INVALID_ARGUMENT, "BVH too deep for the LDS traversal stack");
 
     hipEvent_t t0 = nullptr, t1 = nullptr;
-    if (ctx->timing) { t0 = get_event(ctx); t1 = get_event(ctx); hipEventRecord(t0, ctx->stream); }
+    if (ctx->timing) { t0 = get_event(ctx); t1 = get_event(ctx); hipEventRecord(t0, st); }
 
-    HIP_TRY(hipMemsetAsync(ctx->pb.counts, 0, (size_t)ctx->counts_capacity * LP_SHARDS * sizeof(uint32_t) * 2, ctx->stream));
-    hipLaunchKernelGGL(k_begin, dim3(blocks), dim3(LP_BLOCK), 0, ctx->stream, fp, ctx->pb, n);
+    HIP_TRY(hipMemsetAsync(ln->pb.counts, 0, (size_t)ln->counts_capacity * LP_SHARDS * sizeof(uint32_t) * 2, st));
+    hipLaunchKernelGGL(k_begin, dim3(blocks), dim3(LP_BLOCK), 0, st, fp, ln->pb, n);
     for (uint32_t it = 0; it < iterations; it++)
     {
         switch (pathtrace_type)
         {
-        case LUPIN_PATHTRACE_STANDARD: launch_iteration<LUPIN_PATHTRACE_STANDARD>(ctx, scene, fp, blocks, lds, stack_words, it); break;
-        case LUPIN_PATHTRACE_MIS: launch_iteration<LUPIN_PATHTRACE_MIS>(ctx, scene, fp, blocks, lds, stack_words, it); break;
-        case LUPIN_PATHTRACE_NAIVE: launch_iteration<LUPIN_PATHTRACE_NAIVE>(ctx, scene, fp, blocks, lds, stack_words, it); break;
-        default: launch_iteration<LUPIN_PATHTRACE_DIRECT>(ctx, scene, fp, blocks, lds, stack_words, it); break;
+        case LUPIN_PATHTRACE_STANDARD: launch_iteration<LUPIN_PATHTRACE_STANDARD>(ctx, ln, scene, fp, blocks, lds, stack_words, it); break;
+        case LUPIN_PATHTRACE_MIS: launch_iteration<LUPIN_PATHTRACE_MIS>(ctx, ln, scene, fp, blocks, lds, stack_words, it); break;
+        case LUPIN_PATHTRACE_NAIVE: launch_iteration<LUPIN_PATHTRACE_NAIVE>(ctx, ln, scene, fp, blocks, lds, stack_words, it); break;
+        default: launch_iteration<LUPIN_PATHTRACE_DIRECT>(ctx, ln, scene, fp, blocks, lds, stack_words, it); break;
         }
     }
-    hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(LP_BLOCK), 0, ctx->stream, fp, ctx->pb, n,
+    // The frames meet here: the resolve reads prev_frame and overwrites render_target, so it is ordered after everything
+    // enqueued so far on the other lane (the previous call's resolve) and, for lane 1, on the primary stream (texture
+    // uploads / copies).  The path state itself is private to the lane.
+    if (w != 0)
+    {
+        HIP_TRY(hipEventRecord(ctx->marker, ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(st, ctx->marker, 0));
+    }
+    if (ctx->last_lane >= 0 && ctx->last_lane != w)
+        HIP_TRY(hipStreamWaitEvent(st, ctx->lanes[ctx->last_lane].done, 0));
+    hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(LP_BLOCK), 0, st, fp, ln->pb, n,
                        prev ? prev->data : (const __half *)nullptr, render_target->data);
-    if (ctx->timing) { hipEventRecord(t1, ctx->stream); ctx->ev_total.push_back({t0, t1}); }
+    HIP_TRY(hipEventRecord(ln->done, st));
+    ln->used = true;
+    ctx->last_lane = w;
+    if (ctx->timing) { hipEventRecord(t1, st); ctx->ev_total.push_back({t0, t1}); }
     HIP_TRY(hipGetLastError());
     return LUPIN_OK;
 }
@@ -1932,8 +2003,9 @@ int lupin_hip_stats_reset(LupinContext *ctx, int enable_kernel_timing)
 {
     if (!ctx) return fail(LUPIN_ERR_INVALID_ARGUMENT, "ctx is null");
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipMemsetAsync(ctx->stat_counters, 0, 2 * LP_SHARDS * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(sync_all(ctx));
+    for (int k = 0; k < ctx->num_lanes; k++)
+        HIP_TRY(hipMemsetAsync(ctx->lanes[k].stat_counters, 0, 2 * LP_SHARDS * sizeof(unsigned long long), ctx->lanes[k].stream));
     // extend/shade pairs share their middle event: recycle each event once
     for (auto &p : ctx->ev_extend) { ctx->ev_pool.push_back(p.first); ctx->ev_pool.push_back(p.second); }
     for (auto &p : ctx->ev_shade) { ctx->ev_pool.push_back(p.second); }
@@ -1950,11 +2022,14 @@ int lupin_hip_stats_get(LupinContext *ctx, LupinStats *out)
 {
     if (!ctx || !out) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(sync_all(ctx));
     std::vector<unsigned long long> c(2 * LP_SHARDS, 0ull);
-    HIP_TRY(hipMemcpy(c.data(), ctx->stat_counters, c.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     memset(out, 0, sizeof(*out));
-    for (uint32_t k = 0; k < LP_SHARDS; k++) { out->path_bounces += c[2 * k]; out->paths += c[2 * k + 1]; }
+    for (int l = 0; l < ctx->num_lanes; l++)
+    {
+        HIP_TRY(hipMemcpy(c.data(), ctx->lanes[l].stat_counters, c.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (uint32_t k = 0; k < LP_SHARDS; k++) { out->path_bounces += c[2 * k]; out->paths += c[2 * k + 1]; }
+    }
     out->extend_launches = ctx->extend_launches;
     auto sum = [](const std::vector<std::pair<hipEvent_t, hipEvent_t>> &v) {
         double ms = 0.0;
@@ -2020,6 +2095,7 @@ static int pack_common(LupinContext *ctx, const LupinTexture *tex, uint32_t tile
     if (!ctx || !tex || !packed || tile_size == 0 || world == 0 || rank >= world) return fail(LUPIN_ERR_INVALID_ARGUMENT, "bad pack arguments");
     HIP_TRY(hipSetDevice(ctx->device));
     dim3 block(LP_BLOCK, 1, 1), grid((tex->width + LP_BLOCK - 1) / LP_BLOCK, tex->height, 1);
+    join_primary(ctx);
     hipLaunchKernelGGL(k_pack_tiles, grid, block, 0, ctx->stream, (const uint2 *)tex->data, (uint2 *)packed, tex->width, tex->height,
                        tile_size * LUPIN_WORKGROUP_SIZE, rank, world, unpack);
     HIP_TRY(hipGetLastError());

@@ -111,6 +111,31 @@ def test_tiled_dispatch_matches_oracle_tiles(gpu_ctx):
     assert e.value.code == -5   # "tile_idx out of range!" (renderer.rs:814)
 
 
+def test_overlapped_frames_keep_accumulation_order(gpu_ctx):
+    """Consecutive calls run on alternating lanes (streams) and only meet at the resolve: a long accumulation, a
+    mid-sequence texture upload and copy_front_to_back on the primary stream must give the serial result bit for bit."""
+    scene, cams = util.load_scene("cornellbox_builtin", gpu_ctx)
+    cam = cams[0]
+    W, H, frames = 96, 64, 9
+    want = util.oracle_accumulate(scene, cam, W, H, frames=frames, spp=2, max_bounces=6)
+    got = util.gpu_accumulate(gpu_ctx, scene, cam, W, H, frames=frames, spp=2, max_bounces=6)
+    assert util.f16_words_differ(got, want) == 0
+    # download in the middle, re-upload into the back buffer, continue: same pixels
+    res = api.build_pathtrace_resources(gpu_ctx, api.BakedPathtraceParams(max_bounces=6, samples_per_pixel=2))
+    out = api.DoubleBufferedTexture(gpu_ctx, W, H)
+    for k in range(frames):
+        desc = api.PathtraceDesc(accum_params=api.AccumulationParams(out.back(), k), camera_params=cam.params, camera_transform=cam.transform)
+        api.pathtrace_scene(gpu_ctx, res, scene, out.front(), 0, desc)
+        if k == 3:
+            mid = out.front().download()
+            out.front().upload(mid)
+        if k == 5:
+            out.copy_front_to_back()   # back == front: flipping now changes nothing
+        out.flip()
+    out.flip()
+    assert util.f16_words_differ(out.front().download(), want) == 0
+
+
 def test_error_behaviour(gpu_ctx):
     scene, cams = util.load_scene("cornellbox_builtin", gpu_ctx)
     res = api.build_pathtrace_resources(gpu_ctx, api.BakedPathtraceParams())
