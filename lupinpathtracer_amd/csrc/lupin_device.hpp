@@ -103,6 +103,7 @@ struct SceneDev
     const uint8_t *texels;
     const LupinEnvironment *environments;
     const LupinLight *lights;
+    const float4 *light_bounds;          // per light: conservative world-space sphere (xyz centre, w padded radius)
     const AliasRange *alias_ranges;      // per light
     const AliasRange *env_alias_ranges;  // per environment
     const LupinAliasBin *alias_bins;     // pool
@@ -1399,10 +1400,32 @@ template <typename Geo>
 LP_FN float lights_pdf(const Geo &geo, const SceneDev &sc, uint32_t *stack, f3 pos, f3 incoming, float eps)
 {
     float pdf = 0.0f;
-    // every emissive instance: march the ray through its BLAS (<= 100 crossings), no occlusion test
+    // every emissive instance: march the ray through its BLAS (<= 100 crossings), no occlusion test.
+    // Phase 1 (wave-uniform loop, scalar loads): which lights can this ray reach at all?  Conservative sphere test, the
+    // radius additionally padded by 1e-5 x distance for the rounding of the test itself.  Phase 2: each lane walks its own
+    // candidates in increasing light order, so the sum below has the reference's order and the skipped terms are +0.0f.
     float mesh_pdf = 0.0f;
-    for (uint32_t i = 0; i < sc.num_lights; i++)
+    const float dd = dot3(incoming, incoming);
+    for (uint32_t base = 0; base < sc.num_lights; base += 32u)
     {
+        const uint32_t cnt = (sc.num_lights - base) < 32u ? (sc.num_lights - base) : 32u;
+        uint32_t mask = 0u;
+        for (uint32_t k = 0; k < cnt; k++)
+        {
+            const float4 b = sc.light_bounds[base + k];
+            const f3 v = mk3(b.x - pos.x, b.y - pos.y, b.z - pos.z);
+            const float R = b.w + 1e-5f * (fabsf(v.x) + fabsf(v.y) + fabsf(v.z));
+            const float vv = dot3(v, v);
+            const f3 cr = cross3(v, incoming);
+            const bool behind = dot3(v, incoming) < 0.0f && eps > 0.0f;   // hits need t >= eps
+            const bool reach = behind ? (vv <= R * R) : (dot3(cr, cr) <= R * R * dd);
+            // "not provably out of reach": NaN / inf operands keep the light
+            if (reach || !(vv == vv) || !(R < LP_F32_MAX)) mask |= 1u << k;
+        }
+        while (mask)
+        {
+        const uint32_t i = base + (uint32_t)__builtin_ctz(mask);
+        mask &= mask - 1u;
         const LupinLight light = sc.lights[i];
         const InstanceDev in = geo.inst(light.instance_idx);
         float light_pdf = 0.0f;
@@ -1432,6 +1455,7 @@ LP_FN float lights_pdf(const Geo &geo, const SceneDev &sc, uint32_t *stack, f3 p
             next_pos = add(light_pos, incoming);
         }
         mesh_pdf += light_pdf;
+        }
     }
     pdf += mesh_pdf;
 

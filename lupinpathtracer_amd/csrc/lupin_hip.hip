@@ -287,13 +287,16 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launc
 // least LP_REFILL_MIN of them have finished.  Work is partitioned statically, so refilling needs no atomics: the
 // grid holds `wps` waves per shard, and wave j of shard s owns the 64-entry chunks j, j + wps, j + 2 wps, ... of that
 // shard's queue.  Every ray is still traced exactly as in k_extend, only by a different lane.
-constexpr uint32_t LP_REFILL_MIN = 16;
+#ifndef LP_REFILL_MIN
+#define LP_REFILL_MIN 16
+#endif
 
-template <int TYPE>
+template <int TYPE, bool LDSGEO>
 __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, FrameParams fp, PathBuffers pb, uint32_t iter,
-                                                                unsigned long long *shard_stats)
+                                                                unsigned long long *shard_stats, uint32_t refill_min, uint32_t stack_words)
 {
-    extern __shared__ uint32_t lds_stack[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+    const auto geo = make_geo<LDSGEO>(sc, lds_stack, stack_words);
     static_assert(LP_SHARDS == LP_BLOCK, "block 0 books one shard per thread");
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t *counts = pb.counts + (size_t)iter * LP_SHARDS;
@@ -321,7 +324,6 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, Fra
     float total_dst = 0.0f;
     f3 o = splat(0.0f), d = splat(0.0f), inv_d = splat(0.0f);
     f3 co = o, cd = d, cinv = inv_d;
-    const GeoGlobal geo = geo_global(sc);
     uint32_t sp = 0, blas_base = 0xFFFFFFFFu, cur_inst = 0, cur = REF_DONE;
     Closest best;
     best.t = LP_F32_MAX; best.u = 0.0f; best.v = 0.0f; best.tri = 0u; best.inst = HIT_MISS;
@@ -340,15 +342,26 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, Fra
         cur = lds_stack[sp * LP_BLOCK + tid];
     };
 
+    // Phase scheduling: a lane is at an internal node (N), a TLAS leaf = instance entry (I), a triangle of a BLAS leaf (T),
+    // at the end of a traversal (F) or empty (E).  Every round the wave executes the ONE phase most of its lanes wait for
+    // (wave-uniform branch), so each instruction runs with as many lanes as possible; lanes of other phases just wait.
     for (;;)
     {
-        // ---- refill idle lanes ----
+        const bool isN = active && !(cur & REF_LEAF);
+        const bool isF = active && cur == REF_DONE;
+        const bool isLeaf = active && (cur & REF_LEAF) && cur != REF_DONE;
+        const bool isI = isLeaf && blas_base == 0xFFFFFFFFu;
+        const bool isT = isLeaf && !isI;
         const unsigned long long idle = __ballot(!active);
-        const uint32_t need = (uint32_t)__popcll(idle);
-        if (need >= LP_REFILL_MIN && next_pos < n_mine)
+        const uint32_t cE = (uint32_t)__popcll(idle);
+        const uint32_t cN = (uint32_t)__popcll(__ballot(isN)), cI = (uint32_t)__popcll(__ballot(isI));
+        const uint32_t cT = (uint32_t)__popcll(__ballot(isT)), cF = (uint32_t)__popcll(__ballot(isF));
+
+        if (cE >= refill_min && next_pos < n_mine)
         {
+            // ---- refill empty lanes ----
             const uint32_t my_rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-            const uint32_t take = min(need, n_mine - next_pos);
+            const uint32_t take = min(cE, n_mine - next_pos);
             const bool got = !active && my_rank < take;
             const uint32_t pos = next_pos + my_rank;
             const size_t q_index = shard_base + (size_t)((pos / 64u) * wps + j) * 64u + pos % 64u;
@@ -379,35 +392,63 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, Fra
                     active = true;
                 }
             }
+            continue;
         }
-        if (!__any(active))
-        {
-            if (next_pos >= n_mine) break;
-            continue;   // unreachable in practice: an all-idle wave with work left refills above
-        }
+        if (cE == 64u) break;   // nothing in flight and (see above) nothing left to fetch
 
-        // ---- phase 1: internal nodes of either level ----
-        while (active && !(cur & REF_LEAF))
+        if (cN >= cT && cN >= cI && cN >= cF)
         {
-            const NodeRegs nd = geo.node(blas_base != 0xFFFFFFFFu, cur);
-            float ld = slab_dst(co, cinv, nd.a.x, nd.a.y, nd.a.z, nd.a.w, nd.b.x, nd.b.y);
-            float rd = slab_dst(co, cinv, nd.b.z, nd.b.w, nd.c.x, nd.c.y, nd.c.z, nd.c.w);
-            bool left_first = ld <= rd;
-            bool push_l = ld < best.t, push_r = rd < best.t;
-            uint32_t near_ref = left_first ? nd.left : nd.right;
-            uint32_t far_ref = left_first ? nd.right : nd.left;
-            bool push_near = left_first ? push_l : push_r;
-            bool push_far = left_first ? push_r : push_l;
-            if (push_far) { lds_stack[sp * LP_BLOCK + tid] = far_ref; sp++; }
-            if (push_near) cur = near_ref; else pop();
-        }
-
-        // ---- phase 2: leaves, or the end of a traversal ----
-        if (active)
-        {
-            if (cur == REF_DONE)
+            // ---- N: one internal node of either level ----
+            if (isN)
             {
-                // ray_skip_alpha_stochastically (bvh_custom.wgsl:154-180), one loop iteration per traversal
+                const NodeRegs nd = geo.node(blas_base != 0xFFFFFFFFu, cur);
+                float ld = slab_dst(co, cinv, nd.a.x, nd.a.y, nd.a.z, nd.a.w, nd.b.x, nd.b.y);
+                float rd = slab_dst(co, cinv, nd.b.z, nd.b.w, nd.c.x, nd.c.y, nd.c.z, nd.c.w);
+                bool left_first = ld <= rd;
+                bool push_l = ld < best.t, push_r = rd < best.t;
+                uint32_t near_ref = left_first ? nd.left : nd.right;
+                uint32_t far_ref = left_first ? nd.right : nd.left;
+                bool push_near = left_first ? push_l : push_r;
+                bool push_far = left_first ? push_r : push_l;
+                if (push_far) { lds_stack[sp * LP_BLOCK + tid] = far_ref; sp++; }
+                if (push_near) cur = near_ref; else pop();
+            }
+        }
+        else if (cT >= cI && cT >= cF)
+        {
+            // ---- T: one triangle of a BLAS leaf, first-found wins ties (strict <) ----
+            if (isT)
+            {
+                const uint32_t ti = cur & ~REF_LEAF;
+                const TriVerts tv = geo.tri(ti);
+                TriHit h = tri_dst(co, cd, xyz(tv.v0), xyz(tv.v1), xyz(tv.v2), eps);
+                if (h.t < best.t) { best.t = h.t; best.u = h.u; best.v = h.v; best.tri = ti; best.inst = cur_inst; }
+                if (__float_as_uint(tv.v0.w) & LEAF_END_BITS) pop(); else cur++;
+            }
+        }
+        else if (cI >= cF)
+        {
+            // ---- I: enter an instance (bvh_custom.wgsl:28-37) ----
+            if (isI)
+            {
+                cur_inst = cur & ~REF_LEAF;
+                const InstanceDev in = geo.inst(cur_inst);
+                co = mk3(o.x * in.r0.x + o.y * in.r0.y + o.z * in.r0.z + 1.0f * in.r0.w,
+                         o.x * in.r1.x + o.y * in.r1.y + o.z * in.r1.z + 1.0f * in.r1.w,
+                         o.x * in.r2.x + o.y * in.r2.y + o.z * in.r2.z + 1.0f * in.r2.w);
+                cd = mk3(d.x * in.r0.x + d.y * in.r0.y + d.z * in.r0.z + 0.0f * in.r0.w,
+                         d.x * in.r1.x + d.y * in.r1.y + d.z * in.r1.z + 0.0f * in.r1.w,
+                         d.x * in.r2.x + d.y * in.r2.y + d.z * in.r2.z + 0.0f * in.r2.w);
+                if (!(in.blas_root & REF_LEAF)) cinv = mk3(1.0f / cd.x, 1.0f / cd.y, 1.0f / cd.z);
+                blas_base = sp;
+                cur = in.blas_root;
+            }
+        }
+        else
+        {
+            // ---- F: end of a traversal = one iteration of ray_skip_alpha_stochastically (bvh_custom.wgsl:154-180) ----
+            if (isF)
+            {
                 const bool hit = best.t != LP_F32_MAX;
                 bool again = false;
                 if (hit)
@@ -436,33 +477,6 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, Fra
                     if (rng != rng_in) pb.ori_rng[slot].w = __uint_as_float(rng);
                     active = false;
                 }
-            }
-            else if (blas_base == 0xFFFFFFFFu)
-            {
-                cur_inst = cur & ~REF_LEAF;
-                const InstanceDev in = sc.instances[cur_inst];
-                co = mk3(o.x * in.r0.x + o.y * in.r0.y + o.z * in.r0.z + 1.0f * in.r0.w,
-                         o.x * in.r1.x + o.y * in.r1.y + o.z * in.r1.z + 1.0f * in.r1.w,
-                         o.x * in.r2.x + o.y * in.r2.y + o.z * in.r2.z + 1.0f * in.r2.w);
-                cd = mk3(d.x * in.r0.x + d.y * in.r0.y + d.z * in.r0.z + 0.0f * in.r0.w,
-                         d.x * in.r1.x + d.y * in.r1.y + d.z * in.r1.z + 0.0f * in.r1.w,
-                         d.x * in.r2.x + d.y * in.r2.y + d.z * in.r2.z + 0.0f * in.r2.w);
-                if (!(in.blas_root & REF_LEAF)) cinv = mk3(1.0f / cd.x, 1.0f / cd.y, 1.0f / cd.z);
-                blas_base = sp;
-                cur = in.blas_root;
-            }
-            else
-            {
-                uint32_t ti = cur & ~REF_LEAF;
-                for (;;)
-                {
-                    const TriVerts tv = sc.tris[ti];
-                    TriHit h = tri_dst(co, cd, xyz(tv.v0), xyz(tv.v1), xyz(tv.v2), eps);
-                    if (h.t < best.t) { best.t = h.t; best.u = h.u; best.v = h.v; best.tri = ti; best.inst = cur_inst; }
-                    if (__float_as_uint(tv.v0.w) & LEAF_END_BITS) break;
-                    ti++;
-                }
-                pop();
             }
         }
     }
@@ -1139,8 +1153,10 @@ struct LupinContext
     bool timing = false;
     int store_rounding = 0;        // LUPIN_STORE_ROUND_TOWARD_ZERO
     bool lds_geometry = true;       // LUPIN_LDS_GEOMETRY=0 keeps small scenes in global memory (A/B runs)
-    bool persistent_extend = false; // LUPIN_EXTEND=persistent selects the lane-refill kernel (measured slower)
-    uint32_t resident_blocks = 1024;
+    int persistent_extend = 2;      // LUPIN_EXTEND: "simple" 0 | "persistent" 1 (always) | default 2: persistent for scenes traversed from global memory
+    uint32_t num_cus = 256;
+    int blocks_per_cu_override = 0; // LUPIN_EXTEND_BLOCKS_PER_CU
+    uint32_t refill_min = LP_REFILL_MIN;   // LUPIN_REFILL_MIN
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_extend, ev_shade, ev_total;
     std::vector<hipEvent_t> ev_pool;
     uint64_t extend_launches = 0;
@@ -1172,6 +1188,7 @@ struct LupinScene
     SceneDev dev{};
     std::vector<void *> allocations;
     uint32_t stack_entries = 1;
+    uint32_t persistent_blocks[4] = {0, 0, 0, 0};   // grid of k_extend_persistent per integrator (lazy)
     bool has_sw_bvh = false;
     bool envs_empty = true, lights_empty = true, instances_empty = true;
 };
@@ -1260,9 +1277,20 @@ static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *sc
     hipStream_t st = ln->stream;
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     if (ctx->timing) { e0 = get_event(ctx); e1 = get_event(ctx); e2 = get_event(ctx); hipEventRecord(e0, st); }
-    if (ctx->persistent_extend && !LDSGEO)
-        hipLaunchKernelGGL(k_extend_persistent<TYPE>, dim3(ctx->resident_blocks), dim3(LP_BLOCK), lds, st,
-                           scene->dev, fp, ln->pb, iter, ln->stat_counters);
+    if (ctx->persistent_extend == 1 || (ctx->persistent_extend == 2 && !LDSGEO))
+    {
+        // as many blocks as the device keeps resident with this scene's traversal-stack size (whole waves per shard)
+        uint32_t &pblocks = const_cast<LupinScene *>(scene)->persistent_blocks[TYPE];
+        if (pblocks == 0)
+        {
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extend_persistent<TYPE, LDSGEO>, LP_BLOCK, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+            if (ctx->blocks_per_cu_override > 0) per_cu = ctx->blocks_per_cu_override;
+            pblocks = std::max(64u, ctx->num_cus * (uint32_t)per_cu / 64u * 64u);
+        }
+        hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO>), dim3(pblocks), dim3(LP_BLOCK), lds, st,
+                           scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words);
+    }
     else
         hipLaunchKernelGGL((k_extend<TYPE, LDSGEO>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
     if (ctx->timing) hipEventRecord(e1, st);
@@ -1336,17 +1364,19 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
     if (e != hipSuccess) { delete ctx; return fail(LUPIN_ERR_HIP, std::string("context setup: ") + hipGetErrorString(e)); }
     ctx->stream = ctx->lanes[0].stream;
     const char *ext = getenv("LUPIN_EXTEND");
-    ctx->persistent_extend = (ext && strcmp(ext, "persistent") == 0);
+    if (ext && strcmp(ext, "persistent") == 0) ctx->persistent_extend = 1;
+    else if (ext && strcmp(ext, "simple") == 0) ctx->persistent_extend = 0;
     const char *lg = getenv("LUPIN_LDS_GEOMETRY");
     ctx->lds_geometry = !(lg && strcmp(lg, "0") == 0);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0)
     {
         const char *bpc = getenv("LUPIN_EXTEND_BLOCKS_PER_CU");
-        int per_cu = bpc ? atoi(bpc) : 4;
-        ctx->resident_blocks = (uint32_t)prop.multiProcessorCount * (uint32_t)std::max(1, per_cu);
-        ctx->resident_blocks = std::max(64u, ctx->resident_blocks / 64u * 64u);   // whole waves-per-shard: multiple of LP_SHARDS waves
+        if (bpc) ctx->blocks_per_cu_override = std::max(0, atoi(bpc));
+        ctx->num_cus = (uint32_t)prop.multiProcessorCount;
     }
+    const char *rm = getenv("LUPIN_REFILL_MIN");
+    if (rm) ctx->refill_min = (uint32_t)std::min(64, std::max(1, atoi(rm)));
     *out_ctx = ctx;
     return LUPIN_OK;
 }
@@ -1675,6 +1705,46 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
         if (nb) alias_bins.insert(alias_bins.end(), s.env_alias_tables[i].bins, s.env_alias_tables[i].bins + nb);
     }
 
+    // Conservative world-space bounding sphere of every light instance (all mesh vertices through the inverse of the
+    // stored world->local rows, in double, radius padded): lights_pdf skips lights whose sphere the ray cannot reach.
+    // A skipped light contributes exactly +0.0f in the reference's sum, so results do not change.
+    std::vector<float4> light_bounds(s.num_lights);
+    for (uint32_t i = 0; i < s.num_lights; i++)
+    {
+        const LupinInstance &in = s.instances[s.lights[i].instance_idx];
+        const LupinMeshDesc &m = s.meshes[in.mesh_idx];
+        const float (*r)[4] = in.transpose_inverse_transform.m;   // 3 rows x 4: world -> local
+        const double a = r[0][0], b = r[0][1], c = r[0][2], d = r[1][0], e = r[1][1], f = r[1][2], g = r[2][0], h = r[2][1], k = r[2][2];
+        const double det = a * (e * k - f * h) - b * (d * k - f * g) + c * (d * h - e * g);
+        float4 bound = make_float4(0.0f, 0.0f, 0.0f, INFINITY);   // singular / non-finite transform: never culled
+        if (std::isfinite(det) && det != 0.0 && m.num_verts > 0)
+        {
+            const double inv[3][3] = {{(e * k - f * h) / det, (c * h - b * k) / det, (b * f - c * e) / det},
+                                      {(f * g - d * k) / det, (a * k - c * g) / det, (c * d - a * f) / det},
+                                      {(d * h - e * g) / det, (b * g - a * h) / det, (a * e - b * d) / det}};
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            bool finite = true;
+            for (uint32_t v = 0; v < m.num_verts; v++)
+            {
+                const double q[3] = {m.verts_pos[4 * v + 0] - (double)r[0][3], m.verts_pos[4 * v + 1] - (double)r[1][3], m.verts_pos[4 * v + 2] - (double)r[2][3]};
+                for (int ax = 0; ax < 3; ax++)
+                {
+                    const double w = inv[ax][0] * q[0] + inv[ax][1] * q[1] + inv[ax][2] * q[2];
+                    finite = finite && std::isfinite(w);
+                    lo[ax] = std::min(lo[ax], w); hi[ax] = std::max(hi[ax], w);
+                }
+            }
+            if (finite)
+            {
+                const double cx = 0.5 * (lo[0] + hi[0]), cy = 0.5 * (lo[1] + hi[1]), cz = 0.5 * (lo[2] + hi[2]);
+                const double rad = 0.5 * std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+                const double cmag = std::fabs(cx) + std::fabs(cy) + std::fabs(cz);
+                bound = make_float4((float)cx, (float)cy, (float)cz, (float)(rad * 1.02 + 1e-4 * (cmag + rad) + 1e-6));
+            }
+        }
+        light_bounds[i] = bound;
+    }
+
     // small scenes: one blob [tlas | blas | tris | instances] in 16-byte words for LDS staging
     std::vector<float4> geo_blob;
     uint32_t off_blas = 0, off_tris = 0, off_inst = 0;
@@ -1708,7 +1778,8 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
         (rc = upload(sc, textures, &dv.textures)) || (rc = upload(sc, texels, &dv.texels)) ||
         (rc = upload(sc, envs, &dv.environments)) || (rc = upload(sc, lights, &dv.lights)) ||
         (rc = upload(sc, alias_ranges, &dv.alias_ranges)) || (rc = upload(sc, env_alias_ranges, &dv.env_alias_ranges)) ||
-        (rc = upload(sc, alias_bins, &dv.alias_bins)) || (rc = upload(sc, geo_blob, &dv.geo_blob)))
+        (rc = upload(sc, alias_bins, &dv.alias_bins)) || (rc = upload(sc, geo_blob, &dv.geo_blob)) ||
+        (rc = upload(sc, light_bounds, &dv.light_bounds)))
     {
         lupin_hip_scene_destroy(sc);
         return rc;
