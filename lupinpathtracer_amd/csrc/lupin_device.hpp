@@ -66,7 +66,7 @@ struct InstanceDev
     uint32_t blas_root;   // child reference of the mesh's BLAS root
     uint32_t mat_idx;
     uint32_t mesh_idx;
-    uint32_t flags;       // bit0: opacity may differ from 1 (alpha test needs the material)
+    uint32_t flags;       // bit0: opacity may differ from 1 (alpha test needs the material); bits 8..11: material type
 };
 
 struct MeshDev
@@ -108,6 +108,7 @@ struct SceneDev
     const AliasRange *env_alias_ranges;  // per environment
     const LupinAliasBin *alias_bins;     // pool
     uint32_t num_lights, num_envs, num_instances;
+    uint32_t sort_shade;                 // k_shade sorts each block's paths by material type (scenes with > 1 type)
     // small scenes: [tlas | blas | tris | instances] as one array of 16-byte words that kernels stage in LDS
     const float4 *geo_blob;
     uint32_t geo_blob_words;                       // 0 = scene too large, traverse from global memory
