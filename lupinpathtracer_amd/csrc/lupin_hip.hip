@@ -293,7 +293,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launc
 
 template <int TYPE, bool LDSGEO>
 __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, FrameParams fp, PathBuffers pb, uint32_t iter,
-                                                                unsigned long long *shard_stats, uint32_t refill_min, uint32_t stack_words)
+                                                                unsigned long long *shard_stats, uint32_t refill_min, uint32_t stack_words, uint32_t nsteps)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     const auto geo = make_geo<LDSGEO>(sc, lds_stack, stack_words);
@@ -398,20 +398,25 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, Fra
 
         if (cN >= cT && cN >= cI && cN >= cF)
         {
-            // ---- N: one internal node of either level ----
-            if (isN)
+            // ---- N: internal nodes of either level; keeps stepping while at least half of the voters are still at one ----
+            for (uint32_t r = 0;; r++)
             {
-                const NodeRegs nd = geo.node(blas_base != 0xFFFFFFFFu, cur);
-                float ld = slab_dst(co, cinv, nd.a.x, nd.a.y, nd.a.z, nd.a.w, nd.b.x, nd.b.y);
-                float rd = slab_dst(co, cinv, nd.b.z, nd.b.w, nd.c.x, nd.c.y, nd.c.z, nd.c.w);
-                bool left_first = ld <= rd;
-                bool push_l = ld < best.t, push_r = rd < best.t;
-                uint32_t near_ref = left_first ? nd.left : nd.right;
-                uint32_t far_ref = left_first ? nd.right : nd.left;
-                bool push_near = left_first ? push_l : push_r;
-                bool push_far = left_first ? push_r : push_l;
-                if (push_far) { lds_stack[sp * LP_BLOCK + tid] = far_ref; sp++; }
-                if (push_near) cur = near_ref; else pop();
+                const bool n = active && !(cur & REF_LEAF);
+                if (r > 0 && (r >= nsteps || (uint32_t)__popcll(__ballot(n)) * 2u < cN)) break;
+                if (n)
+                {
+                    const NodeRegs nd = geo.node(blas_base != 0xFFFFFFFFu, cur);
+                    float ld = slab_dst(co, cinv, nd.a.x, nd.a.y, nd.a.z, nd.a.w, nd.b.x, nd.b.y);
+                    float rd = slab_dst(co, cinv, nd.b.z, nd.b.w, nd.c.x, nd.c.y, nd.c.z, nd.c.w);
+                    bool left_first = ld <= rd;
+                    bool push_l = ld < best.t, push_r = rd < best.t;
+                    uint32_t near_ref = left_first ? nd.left : nd.right;
+                    uint32_t far_ref = left_first ? nd.right : nd.left;
+                    bool push_near = left_first ? push_l : push_r;
+                    bool push_far = left_first ? push_r : push_l;
+                    if (push_far) { lds_stack[sp * LP_BLOCK + tid] = far_ref; sp++; }
+                    if (push_near) cur = near_ref; else pop();
+                }
             }
         }
         else if (cT >= cI && cT >= cF)
@@ -1183,6 +1188,7 @@ struct LupinContext
     uint32_t num_cus = 256;
     int blocks_per_cu_override = 0; // LUPIN_EXTEND_BLOCKS_PER_CU
     uint32_t refill_min = LP_REFILL_MIN;   // LUPIN_REFILL_MIN
+    uint32_t node_steps = 4;               // LUPIN_NODE_STEPS: node visits per scheduling round of k_extend_persistent
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_extend, ev_shade, ev_total;
     std::vector<hipEvent_t> ev_pool;
     uint64_t extend_launches = 0;
@@ -1315,7 +1321,7 @@ static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *sc
             pblocks = std::max(64u, ctx->num_cus * (uint32_t)per_cu / 64u * 64u);
         }
         hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO>), dim3(pblocks), dim3(LP_BLOCK), lds, st,
-                           scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words);
+                           scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words, ctx->node_steps);
     }
     else
         hipLaunchKernelGGL((k_extend<TYPE, LDSGEO>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
@@ -1401,6 +1407,8 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
         if (bpc) ctx->blocks_per_cu_override = std::max(0, atoi(bpc));
         ctx->num_cus = (uint32_t)prop.multiProcessorCount;
     }
+    const char *ns = getenv("LUPIN_NODE_STEPS");
+    if (ns) ctx->node_steps = (uint32_t)std::min(16, std::max(1, atoi(ns)));
     const char *rm = getenv("LUPIN_REFILL_MIN");
     if (rm) ctx->refill_min = (uint32_t)std::min(64, std::max(1, atoi(rm)));
     *out_ctx = ctx;
