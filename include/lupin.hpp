@@ -338,6 +338,20 @@ inline void pathtrace_scene_falsecolor(const Device &d, const PathtraceResources
     check(lupin_hip_pathtrace_scene_falsecolor(d.raw(), res.raw(), scene.raw(), render_target.raw(), (uint32_t)type, &c));
 }
 
+// lp::DebugVizType / DebugVizDesc / pathtrace_scene_debug (renderer.rs:950-1041)
+enum class DebugVizType : uint32_t { BVHAABBChecks = 0, BVHTriChecks = 1, NumBounces = 2 };
+struct DebugVizDesc { DebugVizType viz_type = DebugVizType::BVHAABBChecks; float heatmap_min = 0.0f, heatmap_max = 100.0f; bool first_hit_only = false; };
+inline void pathtrace_scene_debug(const Device &d, const PathtraceResources &res, const Scene &scene, TextureRef render_target,
+                                  const DebugVizDesc &debug_desc, const PathtraceDesc &desc)
+{
+    LupinAccumulationParams ap{};
+    LupinTileParams tp{};
+    LupinPathtraceDesc c{};
+    detail::fill_desc(desc, ap, tp, c);
+    const LupinDebugVizDesc dd{(uint32_t)debug_desc.viz_type, debug_desc.heatmap_min, debug_desc.heatmap_max, debug_desc.first_hit_only ? 1u : 0u};
+    check(lupin_hip_pathtrace_scene_debug(d.raw(), res.raw(), scene.raw(), render_target.raw(), &dd, &c));
+}
+
 }  // namespace lp
 
 namespace lpl {

@@ -378,6 +378,25 @@ int lupin_hip_pathtrace_scene_falsecolor(LupinContext *ctx, const LupinPathtrace
                                          const LupinScene *scene, LupinTexture *render_target,
                                          uint32_t falsecolor_type, const LupinPathtraceDesc *desc);
 
+/* renderer.rs:951-964  DebugVizType / DebugVizDesc */
+enum LupinDebugVizType { LUPIN_DEBUG_VIZ_BVH_AABB_CHECKS = 0, LUPIN_DEBUG_VIZ_BVH_TRI_CHECKS = 1, LUPIN_DEBUG_VIZ_NUM_BOUNCES = 2 };
+typedef struct LupinDebugVizDesc
+{
+    uint32_t viz_type;        /* LupinDebugVizType */
+    float    heatmap_min;
+    float    heatmap_max;
+    uint32_t first_hit_only;  /* bool */
+} LupinDebugVizDesc;
+
+/* renderer.rs:966-1041  lp::pathtrace_scene_debug(device, queue, resources, scene, render_target, debug_desc, desc):
+ * pathtrace_debug_main (pathtracer.wgsl:457-503) -- per pixel ONE sample of the first closest-hit query (first_hit_only,
+ * except for NumBounces) or of the whole Standard path; the number of box tests / triangle tests / surface hits becomes
+ * a heat-map colour (get_heatmap_color, :2806-2872).  Same tiling, accumulation and error rules as pathtrace_scene;
+ * baked samples_per_pixel is ignored as in the reference. */
+int lupin_hip_pathtrace_scene_debug(LupinContext *ctx, const LupinPathtraceResources *res, const LupinScene *scene,
+                                    LupinTexture *render_target, const LupinDebugVizDesc *debug_desc,
+                                    const LupinPathtraceDesc *desc);
+
 /* Tile-sharded variant for multi-GPU rendering (extension; the reference renders tiles one
  * sub-dispatch at a time on one device, renderer.rs:807-829): renders, in ONE wavefront launch,
  * every tile t of the frame with t % world == rank (tiles of tile_size*4 pixels, numbered

@@ -123,6 +123,10 @@ class PathtraceDescC(C.Structure):
                 ("advanced", AdvancedParamsC)]
 
 
+class DebugVizDescC(C.Structure):
+    _fields_ = [("viz_type", C.c_uint32), ("heatmap_min", C.c_float), ("heatmap_max", C.c_float), ("first_hit_only", C.c_uint32)]
+
+
 class StatsC(C.Structure):
     _fields_ = [("path_bounces", C.c_uint64), ("paths", C.c_uint64), ("extend_launches", C.c_uint64),
                 ("extend_ms", C.c_double), ("shade_ms", C.c_double), ("total_ms", C.c_double)]
@@ -160,6 +164,7 @@ SYMBOLS = [
     ("lupin_hip_get_num_tiles", _U32, [_U32, _U32, _U32]),
     ("lupin_hip_pathtrace_scene", C.c_int, [_P, _P, _P, _P, _U32, C.POINTER(PathtraceDescC)]),
     ("lupin_hip_pathtrace_scene_falsecolor", C.c_int, [_P, _P, _P, _P, _U32, C.POINTER(PathtraceDescC)]),
+    ("lupin_hip_pathtrace_scene_debug", C.c_int, [_P, _P, _P, _P, C.POINTER(DebugVizDescC), C.POINTER(PathtraceDescC)]),
     ("lupin_hip_pathtrace_scene_tiles", C.c_int, [_P, _P, _P, _P, _U32, C.POINTER(PathtraceDescC), _U32, _U32, _U32]),
     ("lupin_hip_stats_reset", C.c_int, [_P, C.c_int]),
     ("lupin_hip_stats_get", C.c_int, [_P, C.POINTER(StatsC)]),

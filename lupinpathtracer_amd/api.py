@@ -51,6 +51,20 @@ class FalsecolorType(enum.IntEnum):  # renderer.rs:843-870
     Tri = 11
 
 
+class DebugVizType(enum.IntEnum):  # renderer.rs:950-956
+    BVHAABBChecks = 0
+    BVHTriChecks = 1
+    NumBounces = 2
+
+
+@dataclass
+class DebugVizDesc:  # renderer.rs:958-964
+    viz_type: int = DebugVizType.BVHAABBChecks
+    heatmap_min: float = 0.0
+    heatmap_max: float = 100.0
+    first_hit_only: bool = False
+
+
 class MaterialType(enum.IntEnum):  # renderer.rs:126-139
     Matte = 0
     Glossy = 1
@@ -636,6 +650,19 @@ def pathtrace_scene_falsecolor(ctx, resources, scene, render_target, falsecolor_
     c = _desc_to_c(desc, keep)
     check(lib().lupin_hip_pathtrace_scene_falsecolor(ctx.handle, resources.handle, scene.handle, render_target.handle,
                                                      int(falsecolor_type), C.byref(c)))
+
+
+def pathtrace_scene_debug(ctx, resources, scene, render_target, debug_desc, desc):
+    """lp::pathtrace_scene_debug (renderer.rs:966-1041): BVH-cost / bounce-count heat maps."""
+    assert render_target.format() == "Rgba16Float"
+    if scene.handle is None:
+        raise LupinError(_abi_code("LUPIN_ERR_NO_DEVICE"), "scene was built without a device context; there is no CPU fallback")
+    keep = []
+    c = _desc_to_c(desc, keep)
+    dd = _abi.DebugVizDescC(int(debug_desc.viz_type), float(debug_desc.heatmap_min), float(debug_desc.heatmap_max),
+                            1 if debug_desc.first_hit_only else 0)
+    check(lib().lupin_hip_pathtrace_scene_debug(ctx.handle, resources.handle, scene.handle, render_target.handle,
+                                                C.byref(dd), C.byref(c)))
 
 
 def pathtrace_scene_tiles(ctx, resources, scene, render_target, pathtrace_type, desc, tile_size, rank, world):

@@ -259,8 +259,10 @@ struct GeoGlobal
         NodeRegs r; r.a = nd.a; r.b = nd.b; r.c = nd.c; r.left = nd.d.x; r.right = nd.d.y;
         return r;
     }
-    LP_DEV TriVerts tri(uint32_t i) const { return tris[i]; }
+    LP_DEV TriVerts tri(uint32_t i) const { return tris[i]; }           // a triangle TEST fetches through tri()
+    LP_DEV TriVerts tri_fetch(uint32_t i) const { return tris[i]; }     // shading re-reads vertices through tri_fetch()
     LP_DEV InstanceDev inst(uint32_t i) const { return instances[i]; }
+    static constexpr bool kCounting = false;
 };
 
 struct GeoLds
@@ -281,6 +283,8 @@ struct GeoLds
         TriVerts t; t.v0 = f4(p[0]); t.v1 = f4(p[1]); t.v2 = f4(p[2]);
         return t;
     }
+    LP_DEV TriVerts tri_fetch(uint32_t i) const { return tri(i); }
+    static constexpr bool kCounting = false;
     LP_DEV InstanceDev inst(uint32_t i) const
     {
         lds_v4p p = base + off_inst + i * 4u;
@@ -289,6 +293,21 @@ struct GeoLds
         in.blas_root = __float_as_uint(d.x); in.mat_idx = __float_as_uint(d.y); in.mesh_idx = __float_as_uint(d.z); in.flags = __float_as_uint(d.w);
         return in;
     }
+};
+
+// pathtrace_scene_debug (renderer.rs:966, pathtracer.wgsl:457-503) counts box and triangle tests per pixel
+// (RAY_DEBUG_INFO, bvh_custom.wgsl:54,228,243).  Every traversal fetches internal nodes through node() and tested
+// triangles through tri(), so wrapping the accessor counts them without touching the traversal code.
+template <typename Base>
+struct GeoCounting
+{
+    Base base;
+    uint32_t *aabb_checks, *tri_checks;   // the calling thread's counters
+    static constexpr bool kCounting = true;
+    LP_DEV NodeRegs node(bool in_blas, uint32_t i) const { *aabb_checks += 2u; return base.node(in_blas, i); }
+    LP_DEV TriVerts tri(uint32_t i) const { *tri_checks += 1u; return base.tri(i); }
+    LP_DEV TriVerts tri_fetch(uint32_t i) const { return base.tri(i); }
+    LP_DEV InstanceDev inst(uint32_t i) const { return base.inst(i); }
 };
 
 LP_DEV GeoGlobal geo_global(const SceneDev &sc)
@@ -662,7 +681,7 @@ LP_DEV f3 normal_to_world(const InstanceDev &in, f3 n)
 template <typename Geo>
 LP_DEV f3 geometric_normal(const Geo &geo, const InstanceDev &in, uint32_t gtri)
 {
-    const TriVerts tv = geo.tri(gtri);
+    const TriVerts tv = geo.tri_fetch(gtri);
     f3 v0 = xyz(tv.v0), v1 = xyz(tv.v1), v2 = xyz(tv.v2);
     f3 local = normalize3(cross3(sub(v2, v0), sub(v1, v0)));
     return normal_to_world(in, local);
@@ -698,7 +717,7 @@ LP_FN f3 shading_normal(const Geo &geo, const SceneDev &sc, const Surface &s)
             float2 uv2 = sc.texcoords[s.mesh.texcoords_base + s.i2];
             float tu = uv0.x * w + uv1.x * s.u + uv2.x * s.v;
             float tv_ = uv0.y * w + uv1.y * s.u + uv2.y * s.v;
-            const TriVerts tv = geo.tri(s.gtri);
+            const TriVerts tv = geo.tri_fetch(s.gtri);
             f3 p = sub(xyz(tv.v1), xyz(tv.v0));
             f3 q = sub(xyz(tv.v2), xyz(tv.v0));
             float sx = uv1.x - uv0.x, sy = uv2.x - uv0.x;
@@ -1421,7 +1440,8 @@ LP_FN float lights_pdf(const Geo &geo, const SceneDev &sc, uint32_t *stack, f3 p
             const bool behind = dot3(v, incoming) < 0.0f && eps > 0.0f;   // hits need t >= eps
             const bool reach = behind ? (vv <= R * R) : (dot3(cr, cr) <= R * R * dd);
             // "not provably out of reach": NaN / inf operands keep the light
-            if (reach || !(vv == vv) || !(R < LP_F32_MAX)) mask |= 1u << k;
+            // (the debug heat maps count every light's tests, so the counting accessor keeps them all)
+            if (Geo::kCounting || reach || !(vv == vv) || !(R < LP_F32_MAX)) mask |= 1u << k;
         }
         while (mask)
         {

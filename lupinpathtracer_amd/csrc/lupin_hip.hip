@@ -1042,7 +1042,7 @@ __global__ void __launch_bounds__(LP_BLOCK) k_falsecolor(SceneDev sc, FrameParam
         {
             // hit_backside = det > 0 with det = dot(local dir, cross(v1 - v0, v2 - v0)) of the winning triangle
             // (bvh_custom.wgsl:106, pathtracer.wgsl:2933-2935); recomputed from the instance-local direction
-            const TriVerts tv = geo.tri(hit_tri);
+            const TriVerts tv = geo.tri_fetch(hit_tri);
             const f3 ld = mk3(d.x * s.in.r0.x + d.y * s.in.r0.y + d.z * s.in.r0.z + 0.0f * s.in.r0.w,
                               d.x * s.in.r1.x + d.y * s.in.r1.y + d.z * s.in.r1.z + 0.0f * s.in.r1.w,
                               d.x * s.in.r2.x + d.y * s.in.r2.y + d.z * s.in.r2.z + 0.0f * s.in.r2.w);
@@ -1063,6 +1063,96 @@ __global__ void __launch_bounds__(LP_BLOCK) k_falsecolor(SceneDev sc, FrameParam
     }
     const float spp = (float)fp.spp;
     f3 c = mk3(maxf(color.x / spp, 0.0f), maxf(color.y / spp, 0.0f), maxf(color.z / spp, 0.0f));
+    const size_t px = ((size_t)gy * fp.width + gx) * 4;
+    if (fp.pc.accum_counter != 0)
+    {
+        float w = 1.0f / (float)fp.pc.accum_counter;
+        f3 pc = mk3(__half2float(prev[px + 0]), __half2float(prev[px + 1]), __half2float(prev[px + 2]));
+        c = mk3(maxf(pc.x * (1.0f - w) + c.x * w, 0.0f), maxf(pc.y * (1.0f - w) + c.y * w, 0.0f), maxf(pc.z * (1.0f - w) + c.z * w, 0.0f));
+    }
+    if (fp.store_rne) { out[px + 0] = __float2half_rn(c.x); out[px + 1] = __float2half_rn(c.y); out[px + 2] = __float2half_rn(c.z); }
+    else { out[px + 0] = __float2half_rz(c.x); out[px + 1] = __float2half_rz(c.y); out[px + 2] = __float2half_rz(c.z); }
+    out[px + 3] = __float2half_rn(1.0f);
+}
+
+// get_heatmap_color (pathtracer.wgsl:2806-2872): value -> wavelength 380..750 nm -> rgb, gamma 0.8
+__device__ __forceinline__ f3 heatmap_color(float val, float lo, float hi)
+{
+    const float wavelength = 380.0f + 370.0f * maxf(val - lo, 0.0f) / maxf(hi - lo, 0.0f);
+    f3 color = splat(0.0f);
+    if (wavelength <= 380.0f) color = mk3(0.0f, 0.0f, 0.0f);
+    else if (wavelength > 380.0f && wavelength <= 440.0f) color = mk3(-(wavelength - 440.0f) / 60.0f / 3.0f, 0.0f, 0.8f);
+    else if (wavelength >= 440.0f && wavelength <= 490.0f) color = mk3(0.0f, (wavelength - 440.0f) / 50.0f, 1.0f);
+    else if (wavelength >= 490.0f && wavelength <= 510.0f) color = mk3(0.0f, 1.0f, -(wavelength - 510.0f) / 20.0f);
+    else if (wavelength >= 510.0f && wavelength <= 580.0f) color = mk3((wavelength - 510.0f) / 70.0f, 1.0f, 0.0f);
+    else if (wavelength >= 580.0f && wavelength <= 645.0f) color = mk3(1.0f, -(wavelength - 645.0f) / 65.0f, 0.0f);
+    else if (wavelength >= 645.0f && wavelength <= 780.0f) color = mk3(1.0f, 0.0f, 0.0f);
+    else color = splat(1.0f);
+
+    const float gamma = 0.8f;
+    float factor = 1.0f;
+    if (wavelength >= 380.0f && wavelength < 420.0f) factor = 0.3f + 0.7f * (wavelength - 380.0f) / 40.0f;
+    else if (wavelength >= 420.0f && wavelength < 701.0f) factor = 1.0f;
+    else if (wavelength >= 701.0f && wavelength < 781.0f)
+    {
+        factor = 0.3f + 0.7f * (780.0f - wavelength) / 80.0f;
+        return mk3(lpm_powf(color.x + factor * 1.0f, gamma), lpm_powf(color.y + factor * 1.0f, gamma), lpm_powf(color.z + factor * 1.0f, gamma));
+    }
+    else factor = 1.0f;
+    return mk3(lpm_powf(factor * color.x, gamma), lpm_powf(factor * color.y, gamma), lpm_powf(factor * color.z, gamma));
+}
+
+// pathtrace_debug_main (pathtracer.wgsl:457-503): one sample per pixel of either the first closest-hit query or the whole
+// Standard path, as ONE thread (the view is a diagnostic, not a hot path), with the box / triangle tests and the surface
+// hits counted exactly where the reference counts them; the count becomes a heat-map colour.
+template <bool LDSGEO>
+__global__ void __launch_bounds__(LP_BLOCK) k_debug(SceneDev sc, FrameParams fp, uint32_t n, const __half *prev, __half *out, uint32_t stack_words)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+    const auto base_geo = make_geo<LDSGEO>(sc, lds_stack, stack_words);
+    const uint32_t slot = blockIdx.x * LP_BLOCK + threadIdx.x;
+    if (slot >= n) return;
+    uint32_t gx, gy;
+    slot_to_pixel(fp, slot, gx, gy);
+    if (gx >= fp.width || gy >= fp.height) return;
+    const float eps = fp.pc.ray_epsilon;
+    uint32_t aabb_checks = 0, tri_checks = 0, num_bounces = 0;
+    GeoCounting<typename GeoOf<LDSGEO>::type> geo;
+    geo.base = base_geo; geo.aabb_checks = &aabb_checks; geo.tri_checks = &tri_checks;
+
+    PathRegs p;
+    p.rng = rng_seed_for(gy * fp.width + gx, fp.pc.accum_counter);
+    camera_ray(fp, gx, gy, p.rng, p.ori, p.dir);
+    const bool first_hit_only = (fp.pc.flags & LUPIN_FLAG_DEBUG_FIRST_HIT_ONLY) != 0;
+    const bool debug_num_bounces = (fp.pc.flags & LUPIN_FLAG_DEBUG_NUM_BOUNCES) != 0;
+    if (first_hit_only && !debug_num_bounces)
+    {
+        scene_closest(geo, sc, lds_stack, p.ori, p.dir, eps);
+    }
+    else
+    {
+        p.weight = splat(1.0f); p.radiance = splat(0.0f);
+        p.bounce = 0; p.in_medium = false; p.next_emission = true;
+        p.medium.density = splat(0.0f); p.medium.scattering = splat(0.0f); p.medium.anisotropy = 0.0f;
+        for (;;)
+        {
+            float4 hitrec;
+            uint32_t hit_tri;
+            trace_alpha(geo, sc, lds_stack, p.ori, p.dir, p.rng, eps, hitrec, hit_tri);
+            if (__float_as_uint(hitrec.w) != HIT_MISS) num_bounces++;   // DEBUG_NUM_BOUNCES++ (:606-608)
+            ShadowRays sh;
+            sh.v0 = sh.v1 = false;
+            if (!integrate_vertex<LUPIN_PATHTRACE_STANDARD>(geo, sc, lds_stack, fp, p, hitrec, hit_tri, sh)) break;
+            p.bounce++;
+            if (p.bounce > (int)fp.max_bounces) break;
+        }
+    }
+
+    float val = 0.0f;
+    if (fp.pc.flags & LUPIN_FLAG_DEBUG_TRI_CHECKS) val = (float)tri_checks;
+    else if (fp.pc.flags & LUPIN_FLAG_DEBUG_AABB_CHECKS) val = (float)aabb_checks;
+    else if (debug_num_bounces) val = (float)num_bounces;
+    f3 c = heatmap_color(val, fp.pc.heatmap_min, fp.pc.heatmap_max);
     const size_t px = ((size_t)gy * fp.width + gx) * 4;
     if (fp.pc.accum_counter != 0)
     {
@@ -1937,11 +2027,13 @@ int lupin_hip_dbuf_resize(LupinDoubleBufferedTexture *t, uint32_t width, uint32_
 
 static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res, const LupinScene *scene,
                           LupinTexture *render_target, uint32_t pathtrace_type, const LupinPathtraceDesc *desc,
-                          bool tile_set, uint32_t set_tile_size, uint32_t rank, uint32_t world, int falsecolor_type = -1)
+                          bool tile_set, uint32_t set_tile_size, uint32_t rank, uint32_t world, int falsecolor_type = -1,
+                          const LupinDebugVizDesc *debug = nullptr)
 {
     if (!ctx || !res || !scene || !render_target || !desc) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
     if (falsecolor_type < 0 && pathtrace_type > LUPIN_PATHTRACE_DIRECT) return fail(LUPIN_ERR_INVALID_ARGUMENT, "unknown pathtrace_type");
     if (falsecolor_type > 11) return fail(LUPIN_ERR_INVALID_ARGUMENT, "unknown falsecolor_type");
+    if (debug && debug->viz_type > LUPIN_DEBUG_VIZ_NUM_BOUNCES) return fail(LUPIN_ERR_INVALID_ARGUMENT, "unknown viz_type");
     if (!scene->has_sw_bvh) return fail(LUPIN_ERR_NO_SW_BVH, "no software BVH was built for this scene");   // renderer.rs:774-777
     const uint32_t W = render_target->width, H = render_target->height;
     const LupinTexture *prev = desc->accum_params ? desc->accum_params->prev_frame : nullptr;
@@ -1964,7 +2056,15 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
     if (scene->envs_empty) pc.flags |= LUPIN_FLAG_ENVS_EMPTY;
     if (scene->lights_empty) pc.flags |= LUPIN_FLAG_LIGHTS_EMPTY;
     if (scene->instances_empty) pc.flags |= LUPIN_FLAG_INSTANCES_EMPTY;
-    pc.pathtrace_type = falsecolor_type < 0 ? pathtrace_type : 0u;   // get_push_constants leaves the other selector at 0
+    if (debug)   // get_push_constants (renderer.rs:1430-1454)
+    {
+        pc.flags |= debug->viz_type == LUPIN_DEBUG_VIZ_BVH_AABB_CHECKS ? LUPIN_FLAG_DEBUG_AABB_CHECKS
+                  : debug->viz_type == LUPIN_DEBUG_VIZ_BVH_TRI_CHECKS ? LUPIN_FLAG_DEBUG_TRI_CHECKS : LUPIN_FLAG_DEBUG_NUM_BOUNCES;
+        if (debug->first_hit_only) pc.flags |= LUPIN_FLAG_DEBUG_FIRST_HIT_ONLY;
+        pc.heatmap_min = debug->heatmap_min;
+        pc.heatmap_max = debug->heatmap_max;
+    }
+    pc.pathtrace_type = (falsecolor_type < 0 && !debug) ? pathtrace_type : 0u;   // get_push_constants leaves the other selector at 0
     pc.falsecolor_type = falsecolor_type < 0 ? 0u : (uint32_t)falsecolor_type;
     pc.accum_counter = desc->accum_params ? desc->accum_params->accum_counter : 0u;
     pc.max_radiance = desc->advanced.max_radiance;
@@ -2016,7 +2116,7 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
     if (n64 > 0x7FFFFFFFull) return fail(LUPIN_ERR_INVALID_ARGUMENT, "dispatch too large");
     const uint32_t n = (uint32_t)n64;
 
-    if (falsecolor_type >= 0)
+    if (falsecolor_type >= 0 || debug)
     {
         const uint32_t fblocks = (n + LP_BLOCK - 1) / LP_BLOCK;
         const uint32_t fstack_words = scene->stack_entries * LP_BLOCK;
@@ -2025,7 +2125,12 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
         if (flds_bytes > 160 * 1024) return fail(LUPIN_ERR_INVALID_ARGUMENT, "BVH too deep for the LDS traversal stack");
         const __half *pv = prev ? prev->data : (const __half *)nullptr;
         join_primary(ctx);
-        if (flds) hipLaunchKernelGGL(k_falsecolor<true>, dim3(fblocks), dim3(LP_BLOCK), flds_bytes, ctx->stream, scene->dev, fp, n, pv, render_target->data, fstack_words);
+        if (debug)
+        {
+            if (flds) hipLaunchKernelGGL(k_debug<true>, dim3(fblocks), dim3(LP_BLOCK), flds_bytes, ctx->stream, scene->dev, fp, n, pv, render_target->data, fstack_words);
+            else hipLaunchKernelGGL(k_debug<false>, dim3(fblocks), dim3(LP_BLOCK), flds_bytes, ctx->stream, scene->dev, fp, n, pv, render_target->data, fstack_words);
+        }
+        else if (flds) hipLaunchKernelGGL(k_falsecolor<true>, dim3(fblocks), dim3(LP_BLOCK), flds_bytes, ctx->stream, scene->dev, fp, n, pv, render_target->data, fstack_words);
         else hipLaunchKernelGGL(k_falsecolor<false>, dim3(fblocks), dim3(LP_BLOCK), flds_bytes, ctx->stream, scene->dev, fp, n, pv, render_target->data, fstack_words);
         HIP_TRY(hipGetLastError());
         return LUPIN_OK;
@@ -2097,6 +2202,13 @@ int lupin_hip_pathtrace_scene_falsecolor(LupinContext *ctx, const LupinPathtrace
 {
     if (falsecolor_type > 11) return fail(LUPIN_ERR_INVALID_ARGUMENT, "unknown falsecolor_type");
     return pathtrace_impl(ctx, res, scene, render_target, 0, desc, false, 0, 0, 1, (int)falsecolor_type);
+}
+
+int lupin_hip_pathtrace_scene_debug(LupinContext *ctx, const LupinPathtraceResources *res, const LupinScene *scene,
+                                    LupinTexture *render_target, const LupinDebugVizDesc *debug_desc, const LupinPathtraceDesc *desc)
+{
+    if (!debug_desc) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
+    return pathtrace_impl(ctx, res, scene, render_target, 0, desc, false, 0, 0, 1, -1, debug_desc);
 }
 
 int lupin_hip_pathtrace_scene_tiles(LupinContext *ctx, const LupinPathtraceResources *res, const LupinScene *scene,

@@ -219,6 +219,7 @@ struct Counters
     uint64_t material_points = 0, tex_ldr = 0, tex_hdr = 0, light_mesh = 0, light_env = 0;
     uint64_t closest_hit_queries = 0, light_pdf_queries = 0, surface_hits = 0;
     uint64_t normal_fetches = 0, uv_fetches = 0, color_fetches = 0;   // 3-vertex attribute gathers
+    uint64_t debug_num_bounces = 0;   // DEBUG_NUM_BOUNCES (pathtracer.wgsl:583,606-608): surface hits of pathtrace_standard
 };
 
 const int MAX_VOLUMES = 10;                 // :582
@@ -1612,6 +1613,7 @@ struct Inv
                 radiance += weight * sample_environments(ray.dir);
                 break;
             }
+            n.debug_num_bounces++;   // `if DEBUG { DEBUG_NUM_BOUNCES++; }` (:606-608)
 
             bool in_volume = false;
             float volume_dst = hit.dst;
@@ -2125,6 +2127,97 @@ struct Inv
     // ---- pathtrace_main (:220-292), one invocation ----
     // gx, gy already include constants.id_offset. Returns false when the texel is out of bounds
     // (the invocation still runs in the reference; its result is discarded).
+    // get_heatmap_color (:2806-2872)
+    static vec3f get_heatmap_color(float val, float min_, float max_)
+    {
+        const float wavelength = 380.0f + 370.0f * fmax_(val - min_, 0.0f) / fmax_(max_ - min_, 0.0f);
+        vec3f color = v3(0.0f);
+        if (wavelength <= 380.0f) { color.x = 0.0f; color.y = 0.0f; color.z = 0.0f; }
+        else if (wavelength > 380.0f && wavelength <= 440.0f)
+        {
+            color.x = -(wavelength - 440.0f) / (440.0f - 380.0f) / 3.0f;
+            color.y = 0.0f;
+            color.z = 0.8f;
+        }
+        else if (wavelength >= 440.0f && wavelength <= 490.0f)
+        {
+            color.x = 0.0f;
+            color.y = (wavelength - 440.0f) / (490.0f - 440.0f);
+            color.z = 1.0f;
+        }
+        else if (wavelength >= 490.0f && wavelength <= 510.0f)
+        {
+            color.x = 0.0f;
+            color.y = 1.0f;
+            color.z = -(wavelength - 510.0f) / (510.0f - 490.0f);
+        }
+        else if (wavelength >= 510.0f && wavelength <= 580.0f)
+        {
+            color.x = (wavelength - 510.0f) / (580.0f - 510.0f);
+            color.y = 1.0f;
+            color.z = 0.0f;
+        }
+        else if (wavelength >= 580.0f && wavelength <= 645.0f)
+        {
+            color.x = 1.0f;
+            color.y = -(wavelength - 645.0f) / (645.0f - 580.0f);
+            color.z = 0.0f;
+        }
+        else if (wavelength >= 645.0f && wavelength <= 780.0f) { color.x = 1.0f; color.y = 0.0f; color.z = 0.0f; }
+        else color = v3(1.0f);
+
+        // Gamma correct.
+        const float gamma = 0.8f;
+        float factor = 1.0f;
+        const vec3f white = v3(1.0f);
+        if (wavelength >= 380.0f && wavelength < 420.0f) factor = 0.3f + 0.7f * (wavelength - 380.0f) / (float)(420 - 380);
+        else if (wavelength >= 420.0f && wavelength < 701.0f) factor = 1.0f;
+        else if (wavelength >= 701.0f && wavelength < 781.0f)
+        {
+            factor = 0.3f + 0.7f * (780.0f - wavelength) / (float)(780 - 700);
+            vec3f b = color + white * factor;
+            return {lpm_powf(b.x, gamma), lpm_powf(b.y, gamma), lpm_powf(b.z, gamma)};
+        }
+        else factor = 1.0f;
+        vec3f b = color * factor;
+        return {lpm_powf(b.x, gamma), lpm_powf(b.y, gamma), lpm_powf(b.z, gamma)};
+    }
+
+    // ---- pathtrace_debug_main (:457-503), one invocation (DEBUG = true) ----
+    bool pathtrace_debug_main(uint32_t gx, uint32_t gy, uint32_t dim_x, uint32_t dim_y, const uint16_t *prev_frame, float out_rgb[3])
+    {
+        init_rng(gy * dim_x + gx);
+        vec2f ro = random_vec2f();
+        vec2f pixel_offset = {ro.x - 0.5f, ro.y - 0.5f};
+        Ray camera_ray = compute_camera_ray(gx, gy, dim_x, dim_y, pixel_offset);
+
+        const bool first_hit_only = (constants.flags & LUPIN_FLAG_DEBUG_FIRST_HIT_ONLY) != 0;
+        const bool debug_num_bounces = (constants.flags & LUPIN_FLAG_DEBUG_NUM_BOUNCES) != 0;
+        if (first_hit_only && !debug_num_bounces) ray_scene_intersection(camera_ray);
+        else pathtrace_standard(camera_ray);
+
+        // RAY_DEBUG_INFO (bvh_custom.wgsl:54,228,243): every box pair / triangle tested on behalf of this invocation
+        uint64_t num_tri_checks = 0, num_aabb_checks = 0;
+        for (int k = 0; k < 3; k++) { num_tri_checks += n.tri_tests[k]; num_aabb_checks += n.tlas_aabb[k] + n.blas_aabb[k]; }
+        float val = 0.0f;
+        if ((constants.flags & LUPIN_FLAG_DEBUG_TRI_CHECKS) != 0) val = (float)(uint32_t)num_tri_checks;
+        else if ((constants.flags & LUPIN_FLAG_DEBUG_AABB_CHECKS) != 0) val = (float)(uint32_t)num_aabb_checks;
+        else if (debug_num_bounces) val = (float)(uint32_t)n.debug_num_bounces;
+
+        vec3f color = get_heatmap_color(val, constants.heatmap_min, constants.heatmap_max);
+        bool in_bounds = gx < dim_x && gy < dim_y;
+        if (constants.accum_counter != 0 && in_bounds)
+        {
+            float weight = 1.0f / (float)constants.accum_counter;
+            const uint16_t *p = prev_frame + ((size_t)gy * dim_x + gx) * 4;
+            vec3f prev_color = {half_to_float(p[0]), half_to_float(p[1]), half_to_float(p[2])};
+            color = prev_color * (1.0f - weight) + color * weight;
+            color = max3(color, v3(0.0f));
+        }
+        out_rgb[0] = color.x; out_rgb[1] = color.y; out_rgb[2] = color.z;
+        return in_bounds;
+    }
+
     bool pathtrace_main(uint32_t gx, uint32_t gy, uint32_t dim_x, uint32_t dim_y, const uint16_t *prev_frame, float out_rgb[3])
     {
         init_rng(gy * dim_x + gx);
@@ -2196,7 +2289,8 @@ struct OracleCounters
 // prev_frame / out_rgba16f: W*H*4 half floats (row 0 = top); prev_frame may be NULL when
 // accum_counter == 0.  out_rgb_f32 (optional, W*H*3) receives the unquantised colour.
 // store_rounding: 0 = toward zero (what the reference's goldens show), 1 = nearest even.
-// falsecolor != 0 runs pathtrace_falsecolor_main (pathtracer.wgsl:296-452) with constants->falsecolor_type instead.
+// falsecolor == 1 runs pathtrace_falsecolor_main (pathtracer.wgsl:296-452) with constants->falsecolor_type instead,
+// falsecolor == 2 pathtrace_debug_main (:457-503) with the DEBUG flags / heatmap range of the push constants.
 // Texels outside the dispatch are left untouched.  Returns 0 on success.
 int oracle_pathtrace(const LupinSceneDesc *scene, const LupinPushConstants *constants,
                      uint32_t max_bounces, uint32_t samples_per_pixel,
@@ -2227,7 +2321,8 @@ int oracle_pathtrace(const LupinSceneDesc *scene, const LupinPushConstants *cons
                 inv.s = scene; inv.constants = *constants;
                 inv.MAX_BOUNCES = max_bounces; inv.SAMPLES_PER_PIXEL = samples_per_pixel;
                 float rgb[3];
-                if (falsecolor) inv.pathtrace_falsecolor_main(gx, gy, width, height, prev_frame, rgb);
+                if (falsecolor == 2) inv.pathtrace_debug_main(gx, gy, width, height, prev_frame, rgb);
+                else if (falsecolor) inv.pathtrace_falsecolor_main(gx, gy, width, height, prev_frame, rgb);
                 else inv.pathtrace_main(gx, gy, width, height, prev_frame, rgb);
                 size_t o = (size_t)gy * width + gx;
                 out_rgba16f[o * 4 + 0] = to_half(rgb[0]);

@@ -99,12 +99,20 @@ def dispatch_extent(width, height, tile_params=None):
 
 def pathtrace(scene, width, height, camera_params, camera_transform, max_bounces=8, samples_per_pixel=5, pathtrace_type=0,
               accum_counter=0, prev_frame=None, advanced=None, tile_params=None, out=None, num_threads=0, want_f32=False,
-              store_rounding=0, falsecolor_type=None):
+              store_rounding=0, falsecolor_type=None, debug_desc=None):
     """One pathtrace_scene call on the CPU.  Returns (rgba16f (H,W,4) float16, counters dict[, rgb f32])."""
     (ox, oy), gx, gy = dispatch_extent(width, height, tile_params)
     pc = push_constants(scene, camera_params, camera_transform, pathtrace_type, accum_counter, advanced, (ox, oy))
     if falsecolor_type is not None:
         pc.falsecolor_type = int(falsecolor_type)
+        pc.pathtrace_type = 0
+    if debug_desc is not None:   # get_push_constants (renderer.rs:1430-1454)
+        pc.pathtrace_type = 0
+        pc.flags |= {0: 1 << 4, 1: 1 << 3, 2: 1 << 5}[int(debug_desc.viz_type)]
+        if debug_desc.first_hit_only:
+            pc.flags |= 1 << 6
+        pc.heatmap_min = float(debug_desc.heatmap_min)
+        pc.heatmap_max = float(debug_desc.heatmap_max)
     if out is None:
         out = np.zeros((height, width, 4), np.float16)
     f32 = np.zeros((height, width, 3), np.float32) if want_f32 else None
@@ -115,7 +123,7 @@ def pathtrace(scene, width, height, camera_params, camera_transform, max_bounces
     cnt = OracleCounters()
     rc = lib().oracle_pathtrace(C.byref(scene.desc), C.byref(pc), max_bounces, samples_per_pixel, width, height, gx, gy,
                                 _abi.ptr(prev), _abi.ptr(out), _abi.ptr(f32), C.byref(cnt), num_threads, store_rounding,
-                                0 if falsecolor_type is None else 1)
+                                2 if debug_desc is not None else (0 if falsecolor_type is None else 1))
     if rc != 0:
         raise RuntimeError("oracle_pathtrace failed")
     counters = {}

@@ -288,3 +288,37 @@ def test_falsecolor_entry_point(gpu_ctx, name, cam_i):
     assert util.f16_words_differ(tex.download(), ref) == 0
     with pytest.raises(api.LupinError):
         api.pathtrace_scene_falsecolor(gpu_ctx, res, scene, tex, 12, api.PathtraceDesc())
+
+
+@pytest.mark.parametrize("name,cam_i", [("cornellbox_builtin", 0), ("arealights1", 1), ("materials4", 2)])
+def test_debug_heatmap_entry_point(gpu_ctx, name, cam_i):
+    """lp::pathtrace_scene_debug (renderer.rs:966-1041, pathtracer.wgsl:457-503, :2806-2872): box-test, triangle-test
+    and bounce-count heat maps, first-hit-only and whole-path, two accumulation frames, against the oracle.  The
+    colour is a function of an integer count, so equality also pins the per-pixel counts (incl. light-pdf marching,
+    where the product path culls lights and the debug view must not)."""
+    from oracle import oracle
+    scene, cams = util.load_scene(name, gpu_ctx)
+    cam = cams[cam_i]
+    W = 96
+    H = max(4, int(W / cam.params.aspect)) // 4 * 4
+    res = api.build_pathtrace_resources(gpu_ctx, api.BakedPathtraceParams(max_bounces=6, samples_per_pixel=3))
+    cases = [(api.DebugVizType.BVHAABBChecks, True, 0.0, 60.0), (api.DebugVizType.BVHTriChecks, True, 0.0, 20.0),
+             (api.DebugVizType.BVHAABBChecks, False, 0.0, 400.0), (api.DebugVizType.BVHTriChecks, False, 5.0, 150.0),
+             (api.DebugVizType.NumBounces, False, 0.0, 7.0), (api.DebugVizType.NumBounces, True, 0.0, 3.0)]
+    for viz, first, lo, hi in cases:
+        dd = api.DebugVizDesc(viz, lo, hi, first)
+        out = api.DoubleBufferedTexture(gpu_ctx, W, H)
+        prev = np.zeros((H, W, 4), np.float16)
+        for k in range(2):
+            desc = api.PathtraceDesc(accum_params=api.AccumulationParams(out.back(), k), camera_params=cam.params, camera_transform=cam.transform)
+            api.pathtrace_scene_debug(gpu_ctx, res, scene, out.front(), dd, desc)
+            ref, _ = oracle.pathtrace(scene, W, H, cam.params, cam.transform, 6, 3, accum_counter=k, prev_frame=prev, debug_desc=dd)
+            prev = ref
+            out.flip()
+        out.flip()
+        got = out.front().download()
+        assert util.f16_words_differ(got, ref) == 0, f"debug {viz.name} first_hit_only={first} {name}"
+        assert len(np.unique(got[..., :3].astype(np.float32))) > 3   # an actual heat map, not one colour
+    with pytest.raises(api.LupinError):
+        api.pathtrace_scene_debug(gpu_ctx, res, scene, api.Texture(gpu_ctx, W, H), api.DebugVizDesc(7, 0.0, 1.0, False),
+                                  api.PathtraceDesc(camera_params=cam.params, camera_transform=cam.transform))

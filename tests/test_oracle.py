@@ -191,3 +191,24 @@ def test_falsecolor_oracle_sanity(built):
     assert view(api.FalsecolorType.IsDelta)[..., :3].max() == 0.0     # the Cornell box is all matte
     inst = view(api.FalsecolorType.Instance)[..., :3]
     assert len(np.unique(inst.reshape(-1, 3).round(3), axis=0)) >= 6
+
+
+def test_debug_heatmap_restatement():
+    """pathtrace_debug_main / get_heatmap_color (pathtracer.wgsl:457-503, :2806-2872): value <= min is black, the
+    box-test count of a first-hit query on the Cornell box is a small even number, bounce counts stay <= max_bounces + 1."""
+    from lupinpathtracer_amd import api
+    scene, cams = util.load_scene("cornellbox_builtin", None)
+    cam = cams[0]
+    W = H = 32
+    # everything below `min` -> wavelength 380 -> black
+    img, _ = oracle.pathtrace(scene, W, H, cam.params, cam.transform, 4, 1, debug_desc=api.DebugVizDesc(api.DebugVizType.BVHAABBChecks, 1e6, 2e6, True))
+    assert np.all(img[..., :3] == 0) and np.all(img[..., 3] == 1)
+    # a range that puts every pixel in the visible band: colours vary, all finite, none above 1
+    img, cnt = oracle.pathtrace(scene, W, H, cam.params, cam.transform, 4, 1, debug_desc=api.DebugVizDesc(api.DebugVizType.BVHAABBChecks, 0.0, 64.0, True))
+    rgb = img[..., :3].astype(np.float32)
+    assert np.isfinite(rgb).all() and rgb.max() <= 1.0 and len(np.unique(rgb)) > 4
+    per_pixel = (sum(cnt["tlas_aabb"]) + sum(cnt["blas_aabb"])) / (W * H)
+    assert 2 <= per_pixel <= 64 and (sum(cnt["tlas_aabb"]) % 2 == 0)
+    # max == min: 0/0 or x/0 -> the `else` colour (white) through pow(1, 0.8) = 1
+    img, _ = oracle.pathtrace(scene, W, H, cam.params, cam.transform, 4, 1, debug_desc=api.DebugVizDesc(api.DebugVizType.NumBounces, 3.0, 3.0, False))
+    assert set(np.unique(img[..., :3].astype(np.float32))) <= {0.0, 1.0}
