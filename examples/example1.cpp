@@ -3,7 +3,7 @@
 // DoubleBufferedTexture, saved as output.hdr.
 //
 //   g++ -std=c++17 -O2 -Iinclude examples/example1.cpp -Llupinpathtracer_amd -llupin_hip -Wl,-rpath,$PWD/lupinpathtracer_amd -o examples/example1
-//   ./examples/example1 [size=1000] [num_accums=200] [out=output.hdr]
+//   ./examples/example1 [size=1000] [num_accums=200] [out=output.hdr] [preview.ppm]   (preview: tonemapped, sRGB)
 #include <cstdlib>
 #include <iostream>
 
@@ -32,6 +32,12 @@ int main(int argc, char **argv)
         }
         output.flip();
         lpl::save_texture(out_path, output.front());
+        if (argc > 4)   // lp::tonemap_and_fit_aspect with the default TonemapDesc, as the reference's viewer / test app present frames
+        {
+            std::vector<uint8_t> ldr;
+            lp::tonemap_and_fit_aspect(device, output.front(), ldr, size, size);
+            lpl::save_rgba8_ppm(argv[4], ldr, size, size);
+        }
         std::cout << "wrote " << out_path << " (" << size << "x" << size << ", " << num_accums << " x 5 spp)\n";
     }
     catch (const lp::Error &e)

@@ -352,6 +352,19 @@ inline void pathtrace_scene_debug(const Device &d, const PathtraceResources &res
     check(lupin_hip_pathtrace_scene_debug(d.raw(), res.raw(), scene.raw(), render_target.raw(), &dd, &c));
 }
 
+// lp::Viewport / TonemapDesc / tonemap_and_fit_aspect (tonemapping.rs:106-224); the Rgba8Unorm target is a host image
+struct Viewport { float x = 0, y = 0, w = 0, h = 0; };
+struct TonemapDesc { std::optional<Viewport> viewport; float exposure = 0.0f; bool filmic = false; bool srgb = true; bool clear = true; };
+inline void tonemap_and_fit_aspect(const Device &d, TextureRef src, std::vector<uint8_t> &dst_rgba8, uint32_t dst_width, uint32_t dst_height,
+                                   const TonemapDesc &desc = TonemapDesc())
+{
+    dst_rgba8.resize((size_t)dst_width * dst_height * 4);
+    LupinTonemapDesc c{};
+    if (desc.viewport) { c.has_viewport = 1; c.viewport_x = desc.viewport->x; c.viewport_y = desc.viewport->y; c.viewport_w = desc.viewport->w; c.viewport_h = desc.viewport->h; }
+    c.exposure = desc.exposure; c.filmic = desc.filmic ? 1u : 0u; c.srgb = desc.srgb ? 1u : 0u; c.clear = desc.clear ? 1u : 0u;
+    check(lupin_hip_tonemap_and_fit_aspect(d.raw(), src.raw(), dst_rgba8.data(), dst_width, dst_height, &c));
+}
+
 }  // namespace lp
 
 namespace lpl {
@@ -414,6 +427,17 @@ inline float half_to_float(uint16_t h)
     else if (exp == 31) u = sign | 0x7F800000u | (man << 13);
     else u = sign | ((exp + 112) << 23) | (man << 13);
     float f; std::memcpy(&f, &u, 4); return f;
+}
+
+// 8-bit preview of a tonemapped target (lp::tonemap_and_fit_aspect output) as binary PPM; the reference saves Rgba8Unorm
+// textures as RGB8 through the `image` crate (loader.rs:1823-1851), PPM keeps this header dependency-free
+inline void save_rgba8_ppm(const std::string &path, const std::vector<uint8_t> &rgba8, uint32_t w, uint32_t h)
+{
+    FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) throw lp::Error(LUPIN_ERR_INVALID_ARGUMENT, "cannot open " + path);
+    std::fprintf(f, "P6\n%u %u\n255\n", w, h);
+    for (size_t i = 0; i < (size_t)w * h; i++) std::fwrite(&rgba8[i * 4], 1, 3, f);
+    std::fclose(f);
 }
 
 // lpl::save_texture for `.hdr` (loader.rs:1775-1879; alpha dropped): flat RGBE, pixel rule of the `image` crate's encoder

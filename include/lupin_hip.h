@@ -434,6 +434,24 @@ int lupin_hip_trace_rays(LupinContext *ctx, const LupinScene *scene, uint32_t n,
  * result to be bit-identical to the host build of the same header. */
 int lupin_hip_detmath_probe(LupinContext *ctx, int fn, uint32_t n, const float *x, const float *y, float *out);
 
+/* tonemapping.rs:106-132  TonemapDesc (+ Viewport :144-151) */
+typedef struct LupinTonemapDesc
+{
+    uint32_t has_viewport;   /* 0 = None: the whole target */
+    float    viewport_x, viewport_y, viewport_w, viewport_h;
+    float    exposure;       /* color *= 2^exposure */
+    uint32_t filmic;         /* bool, default false */
+    uint32_t srgb;           /* bool, default true */
+    uint32_t clear;          /* bool, default true: target cleared to (0,0,0,1) first */
+} LupinTonemapDesc;
+
+/* tonemapping.rs:155-224  lp::tonemap_and_fit_aspect(device, queue, resources, src, dst, desc) with the Rgba8Unorm
+ * target held by the host: `dst_rgba8` (dst_width x dst_height x 4 bytes, row 0 = top) is read when !clear and
+ * overwritten with the result.  Synchronous.  The reference rasterises a quad and samples through the hardware
+ * sampler, whose sub-texel precision is not specified; this is the same mapping evaluated at pixel centres. */
+int lupin_hip_tonemap_and_fit_aspect(LupinContext *ctx, const LupinTexture *src, uint8_t *dst_rgba8,
+                                     uint32_t dst_width, uint32_t dst_height, const LupinTonemapDesc *desc);
+
 /* Tile-sharded multi-GPU support: pack the pixels of every tile t with t % world == rank (tiles
  * of tile_size*4 pixels, row-major tile order as renderer.rs:816-817) into a dense device
  * buffer / scatter a packed buffer back. Payload layout: tiles in ascending t, each tile

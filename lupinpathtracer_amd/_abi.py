@@ -127,6 +127,11 @@ class DebugVizDescC(C.Structure):
     _fields_ = [("viz_type", C.c_uint32), ("heatmap_min", C.c_float), ("heatmap_max", C.c_float), ("first_hit_only", C.c_uint32)]
 
 
+class TonemapDescC(C.Structure):
+    _fields_ = [("has_viewport", C.c_uint32), ("viewport_x", C.c_float), ("viewport_y", C.c_float), ("viewport_w", C.c_float),
+                ("viewport_h", C.c_float), ("exposure", C.c_float), ("filmic", C.c_uint32), ("srgb", C.c_uint32), ("clear", C.c_uint32)]
+
+
 class StatsC(C.Structure):
     _fields_ = [("path_bounces", C.c_uint64), ("paths", C.c_uint64), ("extend_launches", C.c_uint64),
                 ("extend_ms", C.c_double), ("shade_ms", C.c_double), ("total_ms", C.c_double)]
@@ -170,6 +175,7 @@ SYMBOLS = [
     ("lupin_hip_stats_get", C.c_int, [_P, C.POINTER(StatsC)]),
     ("lupin_hip_trace_rays", C.c_int, [_P, _P, _U32, _P, _P, C.c_float, _P, _P, _P, _P, _P]),
     ("lupin_hip_detmath_probe", C.c_int, [_P, C.c_int, _U32, _P, _P, _P]),
+    ("lupin_hip_tonemap_and_fit_aspect", C.c_int, [_P, _P, _P, _U32, _U32, C.POINTER(TonemapDescC)]),
     ("lupin_hip_pack_tiles", C.c_int, [_P, _P, _U32, _U32, _U32, _P, C.POINTER(C.c_uint64)]),
     ("lupin_hip_unpack_tiles", C.c_int, [_P, _P, _U32, _U32, _U32, _P]),
     ("lupin_hip_packed_tile_pixels", C.c_uint64, [_U32, _U32, _U32, _U32, _U32]),

@@ -65,6 +65,23 @@ class DebugVizDesc:  # renderer.rs:958-964
     first_hit_only: bool = False
 
 
+@dataclass
+class Viewport:  # tonemapping.rs:144-151
+    x: float = 0.0
+    y: float = 0.0
+    w: float = 0.0
+    h: float = 0.0
+
+
+@dataclass
+class TonemapDesc:  # tonemapping.rs:106-132
+    viewport: Optional[Viewport] = None
+    exposure: float = 0.0
+    filmic: bool = False
+    srgb: bool = True
+    clear: bool = True
+
+
 class MaterialType(enum.IntEnum):  # renderer.rs:126-139
     Matte = 0
     Glossy = 1
@@ -663,6 +680,19 @@ def pathtrace_scene_debug(ctx, resources, scene, render_target, debug_desc, desc
                             1 if debug_desc.first_hit_only else 0)
     check(lib().lupin_hip_pathtrace_scene_debug(ctx.handle, resources.handle, scene.handle, render_target.handle,
                                                 C.byref(dd), C.byref(c)))
+
+
+def tonemap_and_fit_aspect(ctx, src, dst_width, dst_height, desc=None, dst=None):
+    """lp::tonemap_and_fit_aspect (tonemapping.rs:155-224): `src` Texture -> (dst_height, dst_width, 4) uint8 (Rgba8Unorm).
+    `dst` = previous target contents, used when desc.clear is False."""
+    desc = desc or TonemapDesc()
+    out = np.zeros((dst_height, dst_width, 4), np.uint8) if dst is None else np.ascontiguousarray(dst, np.uint8).copy()
+    assert out.shape == (dst_height, dst_width, 4)
+    vp = desc.viewport
+    c = _abi.TonemapDescC(0 if vp is None else 1, *( (0.0, 0.0, 0.0, 0.0) if vp is None else (vp.x, vp.y, vp.w, vp.h)),
+                          float(desc.exposure), 1 if desc.filmic else 0, 1 if desc.srgb else 0, 1 if desc.clear else 0)
+    check(lib().lupin_hip_tonemap_and_fit_aspect(ctx.handle, src.handle, ptr(out), dst_width, dst_height, C.byref(c)))
+    return out
 
 
 def pathtrace_scene_tiles(ctx, resources, scene, render_target, pathtrace_type, desc, tile_size, rank, world):

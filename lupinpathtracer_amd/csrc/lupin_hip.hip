@@ -1165,6 +1165,76 @@ __global__ void __launch_bounds__(LP_BLOCK) k_debug(SceneDev sc, FrameParams fp,
     out[px + 3] = __float2half_rn(1.0f);
 }
 
+// tonemap_and_fit_aspect (tonemapping.rs:155-224, tonemapping.wgsl): the reference draws a quad scaled to the source
+// aspect inside a viewport of an Rgba8Unorm target.  As a compute kernel: one thread per target pixel of the scissor
+// rectangle; pixel centres inside the quad sample the source (linear filter, clamp-to-edge), the rest keep the clear
+// colour / the previous contents.  max(.,0) -> * 2^exposure -> filmic (ACES fit) -> linear-to-sRGB -> unorm8.
+struct TonemapArgs
+{
+    uint32_t src_w, src_h, dst_w, dst_h;
+    float vp_x, vp_y, vp_w, vp_h;
+    float scale_x, scale_y, exposure;
+    uint32_t filmic, srgb;
+    uint32_t sc_x0, sc_y0, sc_x1, sc_y1;   // scissor rectangle clipped to the target
+};
+
+__device__ __forceinline__ float3 tonemap_texel(const __half *src, uint32_t w, uint32_t x, uint32_t y)
+{
+    const size_t i = ((size_t)y * w + x) * 4;
+    return make_float3(__half2float(src[i + 0]), __half2float(src[i + 1]), __half2float(src[i + 2]));
+}
+__device__ __forceinline__ float linear_to_srgb1(float c)   // tonemapping.wgsl:73-79
+{
+    const float cutoff = c <= 0.0031308f ? 1.0f : 0.0f;
+    const float higher = 1.055f * lpm_powf(c, 1.0f / 2.4f) - 0.055f;
+    const float lower = c * 12.92f;
+    return higher * (1.0f - cutoff) + lower * cutoff;
+}
+__device__ __forceinline__ float filmic1(float c)            // tonemapping.wgsl:63-71
+{
+    const float hdr = c * 0.6f;
+    const float ldr = (hdr * hdr * 2.51f + hdr * 0.03f) / (hdr * hdr * 2.43f + hdr * 0.59f + 0.14f);
+    return maxf(ldr, 0.0f);
+}
+__device__ __forceinline__ uint32_t unorm8(float c)
+{
+    const float v = clampf(c, 0.0f, 1.0f) * 255.0f;
+    return (uint32_t)rintf(v == v ? v : 0.0f);
+}
+
+__global__ void __launch_bounds__(LP_BLOCK) k_tonemap(TonemapArgs a, const __half *src, uint32_t *dst)
+{
+    const uint32_t x = a.sc_x0 + blockIdx.x * LP_BLOCK + threadIdx.x, y = a.sc_y0 + blockIdx.y;
+    if (x >= a.sc_x1 || y >= a.sc_y1) return;
+    const float fx = ((float)x + 0.5f - a.vp_x) / a.vp_w, fy = ((float)y + 0.5f - a.vp_y) / a.vp_h;
+    const float nx = 2.0f * fx - 1.0f, ny = 1.0f - 2.0f * fy;
+    if (!(fabsf(nx) <= a.scale_x && fabsf(ny) <= a.scale_y)) return;   // outside the quad
+    const float u = (nx / a.scale_x + 1.0f) * 0.5f, v = (1.0f - ny / a.scale_y) * 0.5f;
+    // linear filter, clamp to edge
+    const float sx = u * (float)a.src_w - 0.5f, sy = v * (float)a.src_h - 0.5f;
+    const float x0f = floorf(sx), y0f = floorf(sy);
+    const float tx = sx - x0f, ty = sy - y0f;
+    const int xa = min(max(f2i_sat(x0f), 0), (int)a.src_w - 1), xb = min(max(f2i_sat(x0f) + 1, 0), (int)a.src_w - 1);
+    const int ya = min(max(f2i_sat(y0f), 0), (int)a.src_h - 1), yb = min(max(f2i_sat(y0f) + 1, 0), (int)a.src_h - 1);
+    const float3 p00 = tonemap_texel(src, a.src_w, xa, ya), p10 = tonemap_texel(src, a.src_w, xb, ya);
+    const float3 p01 = tonemap_texel(src, a.src_w, xa, yb), p11 = tonemap_texel(src, a.src_w, xb, yb);
+    const float gx = 1.0f - tx, gy = 1.0f - ty;
+    float c[3] = {(p00.x * gx + p10.x * tx) * gy + (p01.x * gx + p11.x * tx) * ty,
+                  (p00.y * gx + p10.y * tx) * gy + (p01.y * gx + p11.y * tx) * ty,
+                  (p00.z * gx + p10.z * tx) * gy + (p01.z * gx + p11.z * tx) * ty};
+    const float gain = lpm_powf(2.0f, a.exposure);   // exp2(exposure)
+    uint32_t packed = 0xFF000000u;
+    for (int k = 0; k < 3; k++)
+    {
+        float v1 = maxf(c[k], 0.0f);
+        if (a.exposure != 0.0f) v1 *= gain;
+        if (a.filmic) v1 = filmic1(v1);
+        if (a.srgb) v1 = linear_to_srgb1(v1);
+        packed |= unorm8(v1) << (8 * k);
+    }
+    dst[(size_t)y * a.dst_w + x] = packed;
+}
+
 // standalone closest-hit probe (bvh_custom.wgsl:7-110)
 __global__ void __launch_bounds__(LP_BLOCK) k_trace(SceneDev sc, uint32_t n, const float *ori, const float *dir, float eps,
                                                     uint32_t *out_hit, float *out_dst, float *out_uv, uint32_t *out_inst, uint32_t *out_tri)
@@ -2331,6 +2401,52 @@ int lupin_hip_pack_tiles(LupinContext *ctx, const LupinTexture *tex, uint32_t ti
 int lupin_hip_unpack_tiles(LupinContext *ctx, LupinTexture *tex, uint32_t tile_size, uint32_t rank, uint32_t world, const void *device_src)
 {
     return pack_common(ctx, tex, tile_size, rank, world, const_cast<void *>(device_src), 1);
+}
+
+int lupin_hip_tonemap_and_fit_aspect(LupinContext *ctx, const LupinTexture *src, uint8_t *dst_rgba8, uint32_t dst_width, uint32_t dst_height,
+                                     const LupinTonemapDesc *desc)
+{
+    if (!ctx || !src || !dst_rgba8 || !desc || dst_width == 0 || dst_height == 0) return fail(LUPIN_ERR_INVALID_ARGUMENT, "bad tonemap arguments");
+    HIP_TRY(hipSetDevice(ctx->device));
+    TonemapArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src_w = src->width; a.src_h = src->height; a.dst_w = dst_width; a.dst_h = dst_height;
+    if (desc->has_viewport) { a.vp_x = desc->viewport_x; a.vp_y = desc->viewport_y; a.vp_w = desc->viewport_w; a.vp_h = desc->viewport_h; }
+    else { a.vp_x = 0.0f; a.vp_y = 0.0f; a.vp_w = (float)dst_width; a.vp_h = (float)dst_height; }
+    if (!(a.vp_w > 0.0f) || !(a.vp_h > 0.0f) || !(a.vp_x >= 0.0f) || !(a.vp_y >= 0.0f)) return fail(LUPIN_ERR_INVALID_ARGUMENT, "bad viewport");
+    const float src_aspect = (float)src->width / (float)src->height;      // tonemapping.rs:168-174
+    const float dst_aspect = a.vp_w / a.vp_h;
+    if (src_aspect > dst_aspect) { a.scale_x = 1.0f; a.scale_y = dst_aspect / src_aspect; }
+    else { a.scale_x = src_aspect / dst_aspect; a.scale_y = 1.0f; }
+    a.exposure = desc->exposure; a.filmic = desc->filmic ? 1u : 0u; a.srgb = desc->srgb ? 1u : 0u;
+    // set_scissor_rect(viewport.x as u32, viewport.y as u32, viewport.w as u32, viewport.h as u32) (:217)
+    a.sc_x0 = std::min((uint32_t)a.vp_x, dst_width); a.sc_y0 = std::min((uint32_t)a.vp_y, dst_height);
+    a.sc_x1 = (uint32_t)std::min<uint64_t>((uint64_t)a.sc_x0 + (uint32_t)a.vp_w, dst_width);
+    a.sc_y1 = (uint32_t)std::min<uint64_t>((uint64_t)a.sc_y0 + (uint32_t)a.vp_h, dst_height);
+
+    const size_t bytes = (size_t)dst_width * dst_height * 4;
+    uint32_t *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, bytes));
+    join_primary(ctx);
+    hipError_t e;
+    if (desc->clear)   // LoadOp::Clear(0, 0, 0, 1) over the whole attachment
+    {
+        std::vector<uint32_t> clear_px((size_t)dst_width * dst_height, 0xFF000000u);
+        e = hipMemcpyAsync(d, clear_px.data(), bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+    else e = hipMemcpyAsync(d, dst_rgba8, bytes, hipMemcpyHostToDevice, ctx->stream);   // LoadOp::Load
+    if (e == hipSuccess && a.sc_x1 > a.sc_x0 && a.sc_y1 > a.sc_y0)
+    {
+        dim3 grid((a.sc_x1 - a.sc_x0 + LP_BLOCK - 1) / LP_BLOCK, a.sc_y1 - a.sc_y0, 1);
+        hipLaunchKernelGGL(k_tonemap, grid, dim3(LP_BLOCK), 0, ctx->stream, a, src->data, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(dst_rgba8, d, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(d);
+    if (e != hipSuccess) return fail(LUPIN_ERR_HIP, hipGetErrorString(e));
+    return LUPIN_OK;
 }
 
 }  // extern "C"

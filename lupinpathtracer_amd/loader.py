@@ -194,6 +194,10 @@ def load_texture_pixels(path):
 def save_texture(path, texture_or_array):
     """lpl::save_texture for `.hdr` (loader.rs:1775-1879; alpha dropped) -- accepts an api.Texture or (H,W,>=3)."""
     arr = texture_or_array.download() if hasattr(texture_or_array, "download") else np.asarray(texture_or_array)
+    if arr.dtype == np.uint8:   # Rgba8Unorm (a tonemapped target): 8-bit RGB by file extension (loader.rs:1823-1851)
+        from PIL import Image
+        Image.fromarray(np.ascontiguousarray(arr[..., :3])).save(path)
+        return
     write_hdr(path, arr[..., :3].astype(np.float32))
 
 

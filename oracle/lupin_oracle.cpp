@@ -2413,6 +2413,69 @@ void oracle_bsdf_probe(uint32_t mat_type, const float color[3], float roughness,
     *out_pdf = pdf;
 }
 
+// tonemap_and_fit_aspect (tonemapping.rs:155-224 + tonemapping.wgsl) evaluated at target pixel centres: viewport /
+// scissor (:163-167,:216-217), aspect-fit scale of the quad (:168-174), vertex positions pos * scale with tex coords
+// 0..1 (wgsl:24-48), fragment: clamp-to-edge linear sample, max(.,0), * exp2(exposure), tonemap_filmic,
+// linear_to_srgb (wgsl:51-79), Rgba8Unorm store.  viewport = NULL means the whole target.
+int oracle_tonemap(const uint16_t *src_rgba16f, uint32_t src_w, uint32_t src_h, uint8_t *dst_rgba8, uint32_t dst_w, uint32_t dst_h,
+                   const float *viewport_xywh, float exposure, int filmic, int srgb, int clear)
+{
+    if (!src_rgba16f || !dst_rgba8 || !src_w || !src_h || !dst_w || !dst_h) return -1;
+    float vx = 0.0f, vy = 0.0f, vw = (float)dst_w, vh = (float)dst_h;
+    if (viewport_xywh) { vx = viewport_xywh[0]; vy = viewport_xywh[1]; vw = viewport_xywh[2]; vh = viewport_xywh[3]; }
+    const float src_aspect = (float)src_w / (float)src_h;
+    const float dst_aspect = vw / vh;
+    float scale_x, scale_y;
+    if (src_aspect > dst_aspect) { scale_x = 1.0f; scale_y = dst_aspect / src_aspect; }
+    else { scale_x = src_aspect / dst_aspect; scale_y = 1.0f; }
+    if (clear)
+        for (size_t i = 0; i < (size_t)dst_w * dst_h; i++) { dst_rgba8[i * 4 + 0] = 0; dst_rgba8[i * 4 + 1] = 0; dst_rgba8[i * 4 + 2] = 0; dst_rgba8[i * 4 + 3] = 255; }
+    const uint32_t x0 = std::min((uint32_t)vx, dst_w), y0 = std::min((uint32_t)vy, dst_h);
+    const uint32_t x1 = (uint32_t)std::min<uint64_t>((uint64_t)x0 + (uint32_t)vw, dst_w), y1 = (uint32_t)std::min<uint64_t>((uint64_t)y0 + (uint32_t)vh, dst_h);
+    auto texel = [&](int x, int y, int c) { return half_to_float(src_rgba16f[((size_t)y * src_w + x) * 4 + c]); };
+    auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    const float gain = lpm_powf(2.0f, exposure);
+    for (uint32_t y = y0; y < y1; y++)
+        for (uint32_t x = x0; x < x1; x++)
+        {
+            const float fx = ((float)x + 0.5f - vx) / vw, fy = ((float)y + 0.5f - vy) / vh;
+            const float nx = 2.0f * fx - 1.0f, ny = 1.0f - 2.0f * fy;
+            if (!(fabsf(nx) <= scale_x && fabsf(ny) <= scale_y)) continue;
+            const float u = (nx / scale_x + 1.0f) * 0.5f, v = (1.0f - ny / scale_y) * 0.5f;
+            const float sx = u * (float)src_w - 0.5f, sy = v * (float)src_h - 0.5f;
+            const float x0f = floorf(sx), y0f = floorf(sy);
+            const float tx = sx - x0f, ty = sy - y0f;
+            const int xa = clampi(f2i(x0f), 0, (int)src_w - 1), xb = clampi(f2i(x0f) + 1, 0, (int)src_w - 1);
+            const int ya = clampi(f2i(y0f), 0, (int)src_h - 1), yb = clampi(f2i(y0f) + 1, 0, (int)src_h - 1);
+            const float gx = 1.0f - tx, gy = 1.0f - ty;
+            uint8_t *o = dst_rgba8 + ((size_t)y * dst_w + x) * 4;
+            for (int c = 0; c < 3; c++)
+            {
+                float col = (texel(xa, ya, c) * gx + texel(xb, ya, c) * tx) * gy + (texel(xa, yb, c) * gx + texel(xb, yb, c) * tx) * ty;
+                col = fmax_(col, 0.0f);
+                if (exposure != 0.0f) col *= gain;
+                if (filmic)
+                {
+                    const float hdr = col * 0.6f;
+                    const float ldr = (hdr * hdr * 2.51f + hdr * 0.03f) / (hdr * hdr * 2.43f + hdr * 0.59f + 0.14f);
+                    col = fmax_(ldr, 0.0f);
+                }
+                if (srgb)
+                {
+                    const float cutoff = col <= 0.0031308f ? 1.0f : 0.0f;
+                    const float higher = 1.055f * lpm_powf(col, 1.0f / 2.4f) - 0.055f;
+                    const float lower = col * 12.92f;
+                    col = higher * (1.0f - cutoff) + lower * cutoff;
+                }
+                float q = clamp_(col, 0.0f, 1.0f) * 255.0f;
+                if (!(q == q)) q = 0.0f;
+                o[c] = (uint8_t)rintf(q);
+            }
+            o[3] = 255;
+        }
+    return 0;
+}
+
 uint16_t oracle_float_to_half(float f) { return float_to_half_rne(f); }
 uint16_t oracle_float_to_half_rtz(float f) { return float_to_half_rtz(f); }
 float oracle_half_to_float(uint16_t h) { return half_to_float(h); }

@@ -55,6 +55,9 @@ def lib():
         h.oracle_half_to_float.restype = C.c_float
         h.oracle_half_to_float.argtypes = [C.c_uint16]
         h.oracle_num_threads.restype = C.c_int
+        h.oracle_tonemap.restype = C.c_int
+        h.oracle_tonemap.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
+                                     C.c_float, C.c_int, C.c_int, C.c_int]
         _lib = h
     return _lib
 
@@ -169,3 +172,20 @@ def bsdf_probe(mat_type, color, roughness, metallic, ior, normal, outgoing, rnl,
 
 def num_threads():
     return int(lib().oracle_num_threads())
+
+
+def tonemap(src_rgba16f, dst_width, dst_height, desc=None, dst=None):
+    """tonemap_and_fit_aspect (tonemapping.rs:155-224) on the CPU: (H,W,4) float16 -> (dst_height,dst_width,4) uint8.
+    `desc` is an api.TonemapDesc; `dst` the previous target contents (used when desc.clear is False)."""
+    from lupinpathtracer_amd import api
+    desc = desc or api.TonemapDesc()
+    src = np.ascontiguousarray(src_rgba16f, np.float16)
+    out = np.zeros((dst_height, dst_width, 4), np.uint8) if dst is None else np.ascontiguousarray(dst, np.uint8).copy()
+    vp = None
+    if desc.viewport is not None:
+        vp = np.array([desc.viewport.x, desc.viewport.y, desc.viewport.w, desc.viewport.h], np.float32)
+    rc = lib().oracle_tonemap(_abi.ptr(src), src.shape[1], src.shape[0], _abi.ptr(out), dst_width, dst_height, _abi.ptr(vp),
+                              float(desc.exposure), int(bool(desc.filmic)), int(bool(desc.srgb)), int(bool(desc.clear)))
+    if rc != 0:
+        raise RuntimeError("oracle_tonemap failed")
+    return out

@@ -34,7 +34,8 @@ def test_example1_matches_python_host(gpu_ctx, example1, tmp_path):
     from lupinpathtracer_amd import loader
     from tests import util
     out = str(tmp_path / "output.hdr")
-    subprocess.check_call([example1, "64", "6", out])
+    preview = str(tmp_path / "preview.ppm")
+    subprocess.check_call([example1, "64", "6", out, preview])
     cpp = loader.read_hdr(out)
     scene, cams = util.load_scene("cornellbox_builtin", gpu_ctx)
     img = util.gpu_accumulate(gpu_ctx, scene, cams[0], 64, 64, frames=6, spp=5)
@@ -43,3 +44,11 @@ def test_example1_matches_python_host(gpu_ctx, example1, tmp_path):
     ref = loader.read_hdr(ref_path)
     assert cpp.shape == ref.shape == (64, 64, 3)
     assert np.array_equal(cpp, ref)
+    # the tonemapped preview (lp::tonemap_and_fit_aspect through the C++ mirror) equals the Python host's
+    from lupinpathtracer_amd import api
+    raw = open(preview, "rb").read()
+    assert raw.startswith(b"P6\n64 64\n255\n")
+    ppm = np.frombuffer(raw[len(b"P6\n64 64\n255\n"):], np.uint8).reshape(64, 64, 3)
+    tex = api.Texture(gpu_ctx, 64, 64)
+    tex.upload(img)
+    assert np.array_equal(ppm, api.tonemap_and_fit_aspect(gpu_ctx, tex, 64, 64)[..., :3])

@@ -322,3 +322,22 @@ def test_debug_heatmap_entry_point(gpu_ctx, name, cam_i):
     with pytest.raises(api.LupinError):
         api.pathtrace_scene_debug(gpu_ctx, res, scene, api.Texture(gpu_ctx, W, H), api.DebugVizDesc(7, 0.0, 1.0, False),
                                   api.PathtraceDesc(camera_params=cam.params, camera_transform=cam.transform))
+
+
+def test_tonemap_and_fit_aspect(gpu_ctx):
+    """lp::tonemap_and_fit_aspect (tonemapping.rs:155-224): k_tonemap against the oracle's restatement, byte for byte,
+    on a rendered Cornell frame: default desc, letterboxed targets, viewport, exposure + filmic, clear=False."""
+    from oracle import oracle
+    scene, cams = util.load_scene("cornellbox_builtin", gpu_ctx)
+    img = util.gpu_accumulate(gpu_ctx, scene, cams[0], 96, 64, frames=2, spp=4)
+    tex = api.Texture(gpu_ctx, 96, 64)
+    tex.upload(img)
+    prev = np.random.default_rng(3).integers(0, 255, (120, 100, 4), dtype=np.uint8)
+    cases = [(96, 64, api.TonemapDesc(), None), (200, 90, api.TonemapDesc(), None), (50, 120, api.TonemapDesc(exposure=1.5, filmic=True), None),
+             (100, 120, api.TonemapDesc(viewport=api.Viewport(7, 11, 80, 33), exposure=-0.75, clear=False), prev),
+             (100, 120, api.TonemapDesc(viewport=api.Viewport(40.5, 60.25, 300, 300), srgb=False), None)]
+    for w, h, desc, dst in cases:
+        got = api.tonemap_and_fit_aspect(gpu_ctx, tex, w, h, desc, dst)
+        want = oracle.tonemap(img, w, h, desc, dst)
+        assert np.array_equal(got, want), (w, h, desc)
+    assert got[..., :3].max() > 0
