@@ -85,3 +85,31 @@ def test_packed_tile_pixels_partition(built):
     for (w, h, ts, world) in [(1024, 1024, 16, 8), (1920, 1080, 25, 4), (100, 37, 3, 3), (64, 64, 16, 5)]:
         total = sum(api.packed_tile_pixels(w, h, ts, r, world) for r in range(world))
         assert total == w * h
+
+
+def test_rust_shim_declares_only_header_symbols_with_matching_struct_sizes():
+    """integration/rust/lupin_hip/src/ffi.rs (source only: no Rust toolchain here) must bind existing entry points, and
+    every #[repr(C)] struct it declares must have the C struct's field count and byte size."""
+    import re
+    import ctypes as C
+    from lupinpathtracer_amd import _abi
+    src = open(os.path.join(ROOT, "integration", "rust", "lupin_hip", "src", "ffi.rs")).read()
+    header = open(os.path.join(ROOT, "include", "lupin_hip.h")).read()
+    fns = re.findall(r"pub fn (lupin_\w+)\(", src)
+    assert len(fns) >= 30
+    for f in fns:
+        assert re.search(r"\b%s\(" % f, header), f
+    for must in ("lupin_hip_pathtrace_scene", "lupin_hip_build_pathtrace_resources", "lupin_hip_scene_create", "lupin_hip_dbuf_flip"):
+        assert must in fns
+    size = {"u32": 4, "f32": 4, "LupinMat3x4": 48, "LupinMat4x3": 48, "LupinMat4": 64}
+    want = {"LupinMeshInfo": 12, "LupinInstance": 64, "LupinMaterial": 96, "LupinEnvironment": 80, "LupinLight": 8, "LupinAliasBin": 12,
+            "LupinBvhNode": 32, "LupinTlasNode": 48, "LupinBakedPathtraceParams": 12, "LupinCameraParams": 24, "LupinAdvancedParams": 12,
+            "LupinTileParams": 8, "LupinDebugVizDesc": 16, "LupinTonemapDesc": 36}
+    for name, nbytes in want.items():
+        body = re.search(r"pub struct %s \{(.*?)\}" % name, src, re.S).group(1)
+        total = 0
+        for ty in re.findall(r"pub \w+: ([^,]+?)\s*(?:,|$)", body.strip()):
+            m = re.fullmatch(r"\[(\w+); (\d+)\]", ty.strip())
+            total += size[m.group(1)] * int(m.group(2)) if m else size[ty.strip()]
+        assert total == nbytes, (name, total, nbytes)
+    assert C.sizeof(_abi.TonemapDescC) == 36 and C.sizeof(_abi.DebugVizDescC) == 16
