@@ -468,6 +468,16 @@ uint64_t lupin_hip_packed_tile_pixels(uint32_t width, uint32_t height, uint32_t 
  * Pure host code, no device needed.
  * ---------------------------------------------------------------------------------------- */
 
+/* Device BLAS builder ("next" row 8f-1; no counterpart in the reference, whose builder is CPU-only,
+ * data_structures.rs:196-475): a linear BVH over Morton-sorted triangles -- a complete binary tree with 1-2 triangles
+ * per leaf, depth lupin_hip_lbvh_depth(n) <= 22 -- written in the reference's BvhNode format with the reordered index
+ * buffer, i.e. a drop-in alternative to lupin_build_bvh for lupin_hip_scene_create.  Returns the node count
+ * (= lupin_hip_lbvh_node_count(num_indices / 3)) or a negative status.  Synchronous. */
+uint32_t lupin_hip_lbvh_depth(uint32_t num_tris);
+uint64_t lupin_hip_lbvh_node_count(uint32_t num_tris);
+int64_t lupin_hip_build_bvh_device(LupinContext *ctx, const float *verts_pos4, uint32_t num_verts, uint32_t *indices,
+                                   uint32_t num_indices, LupinBvhNode *out_nodes, uint64_t out_capacity);
+
 /* build_bvh (data_structures.rs:196-235): reorders `indices` in place; returns node count or <0.
  * out_nodes may be NULL to query the count (indices untouched in that case). */
 int64_t lupin_build_bvh(const float *verts_pos4, uint32_t num_verts, uint32_t *indices,

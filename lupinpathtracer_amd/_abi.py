@@ -176,6 +176,9 @@ SYMBOLS = [
     ("lupin_hip_trace_rays", C.c_int, [_P, _P, _U32, _P, _P, C.c_float, _P, _P, _P, _P, _P]),
     ("lupin_hip_detmath_probe", C.c_int, [_P, C.c_int, _U32, _P, _P, _P]),
     ("lupin_hip_tonemap_and_fit_aspect", C.c_int, [_P, _P, _P, _U32, _U32, C.POINTER(TonemapDescC)]),
+    ("lupin_hip_lbvh_depth", _U32, [_U32]),
+    ("lupin_hip_lbvh_node_count", C.c_uint64, [_U32]),
+    ("lupin_hip_build_bvh_device", C.c_int64, [_P, _P, _U32, _P, _U32, _P, C.c_uint64]),
     ("lupin_hip_pack_tiles", C.c_int, [_P, _P, _U32, _U32, _U32, _P, C.POINTER(C.c_uint64)]),
     ("lupin_hip_unpack_tiles", C.c_int, [_P, _P, _U32, _U32, _U32, _P]),
     ("lupin_hip_packed_tile_pixels", C.c_uint64, [_U32, _U32, _U32, _U32, _U32]),

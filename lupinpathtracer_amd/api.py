@@ -415,6 +415,20 @@ def build_bvh(verts_pos, indices):
     return nodes, idx
 
 
+def build_bvh_device(ctx, verts_pos, indices):
+    """Device BLAS builder (csrc/lbvh.hip): Morton-sorted complete binary tree in the reference's BvhNode format.
+    Returns (nodes, reordered indices) like build_bvh; needs a GPU context."""
+    verts = np.ascontiguousarray(verts_pos, np.float32).reshape(-1, 4)
+    idx = np.ascontiguousarray(indices, np.uint32).copy()
+    count = int(lib().lupin_hip_lbvh_node_count(len(idx) // 3))
+    nodes = np.zeros(count, BVH_NODE_DTYPE)
+    n2 = lib().lupin_hip_build_bvh_device(ctx.handle, ptr(verts), len(verts), ptr(idx), len(idx), ptr(nodes), count)
+    if n2 < 0:
+        check(int(n2))
+    assert n2 == count
+    return nodes, idx
+
+
 def build_tlas(instances, model_aabbs):
     """lp::build_tlas (data_structures.rs:545-641). model_aabbs: (num_meshes, 6)."""
     inst = np.ascontiguousarray(instances)
@@ -503,12 +517,19 @@ def _array_of(struct, items):
 
 
 def build_accel_structures_and_upload(ctx, scene: SceneCPU, textures: List[TextureCPU], envs_info: List[EnvMapInfo],
-                                      build_sw_and_hw: bool = True) -> Scene:
+                                      build_sw_and_hw: bool = True, blas_builder: str = "sah") -> Scene:
     """lp::build_accel_structures_and_upload (data_structures.rs:696-872), software-BVH pipeline.
 
     ctx may be None: the host-side preprocessing still runs and `Scene.desc` is usable (CPU-only
     tests feed it to the oracle); nothing is uploaded then.
+    blas_builder: "sah" = the reference's CPU builder (lupin_build_bvh), "lbvh" = the device builder
+    (build_bvh_device; meshes with at least 64 triangles, smaller ones keep the SAH builder); a callable
+    (verts (N,4), indices) -> (nodes, reordered indices) plugs in any other builder that emits the reference's node format.
     """
+    if not callable(blas_builder) and blas_builder not in ("sah", "lbvh"):
+        raise ValueError("blas_builder must be 'sah', 'lbvh' or a callable (verts, indices) -> (nodes, reordered indices)")
+    if blas_builder == "lbvh" and ctx is None:
+        raise LupinError(_abi_code("LUPIN_ERR_NO_DEVICE"), "the device BLAS builder needs a GPU context")
     out = Scene()
     keep = out._keep
 
@@ -519,7 +540,13 @@ def build_accel_structures_and_upload(ctx, scene: SceneCPU, textures: List[Textu
     total_tris = 0
     for verts, indices in zip(scene.verts_pos_array, scene.indices_array):
         v = np.ascontiguousarray(verts, np.float32).reshape(-1, 4)
-        nodes, reordered = build_bvh(v, indices)
+        if callable(blas_builder):
+            nodes, reordered = blas_builder(v, indices)
+            nodes, reordered = np.ascontiguousarray(nodes, BVH_NODE_DTYPE), np.ascontiguousarray(reordered, np.uint32)
+        elif blas_builder == "lbvh" and len(indices) >= 3 * 64:
+            nodes, reordered = build_bvh_device(ctx, v, indices)
+        else:
+            nodes, reordered = build_bvh(v, indices)
         keep += [v, nodes, reordered]
         mesh_descs.append(_abi.MeshDesc(ptr(v), len(v), ptr(reordered), len(reordered), ptr(nodes), len(nodes)))
         total_tris += len(reordered) // 3

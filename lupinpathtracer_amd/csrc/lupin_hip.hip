@@ -1519,6 +1519,11 @@ static hipError_t sync_all(LupinContext *ctx)
     return e;
 }
 
+#include "lupin_internal.hpp"
+int lupin_internal_fail(int code, const char *msg) { return fail(code, msg); }
+int lupin_internal_ctx_device(const LupinContext *ctx) { return ctx->device; }
+hipStream_t lupin_internal_ctx_stream(const LupinContext *ctx) { return ctx->stream; }
+
 extern "C" {
 
 const char *lupin_hip_last_error(void) { return g_last_error.c_str(); }

@@ -479,10 +479,10 @@ def load_scene_cpu_yoctogl_v24(path, asset_dirs: Sequence[str] = ()):
     return scene, textures, envs_info, cams
 
 
-def load_scene_yoctogl_v24(path, ctx, build_both_bvhs=True, asset_dirs: Sequence[str] = ()):
+def load_scene_yoctogl_v24(path, ctx, build_both_bvhs=True, asset_dirs: Sequence[str] = (), blas_builder="sah"):
     """lpl::load_scene_yoctogl_v24 (loader.rs:331) -> (Scene, [SceneCamera])"""
     scene_cpu, textures, envs_info, cams = load_scene_cpu_yoctogl_v24(path, asset_dirs)
-    return api.build_accel_structures_and_upload(ctx, scene_cpu, textures, envs_info, build_both_bvhs), cams
+    return api.build_accel_structures_and_upload(ctx, scene_cpu, textures, envs_info, build_both_bvhs, blas_builder=blas_builder), cams
 
 
 def build_scene_bistro_class_cpu(asset_dir, seed=0xB157, n_meshes=20, n_instances=400, n_lights=100, n_materials=60):
@@ -605,9 +605,9 @@ def build_scene_bistro_class_cpu(asset_dir, seed=0xB157, n_meshes=20, n_instance
     return scene, textures, envs_info, [cam]
 
 
-def build_scene_bistro_class(ctx, asset_dir, **kw):
+def build_scene_bistro_class(ctx, asset_dir, blas_builder="sah", **kw):
     scene_cpu, textures, envs_info, cams = build_scene_bistro_class_cpu(asset_dir, **kw)
-    return api.build_accel_structures_and_upload(ctx, scene_cpu, textures, envs_info, True), cams
+    return api.build_accel_structures_and_upload(ctx, scene_cpu, textures, envs_info, True, blas_builder=blas_builder), cams
 
 
 def compute_dimensions_for_1080p(aspect):

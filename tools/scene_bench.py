@@ -24,12 +24,21 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--type", type=int, default=0)
+    ap.add_argument("--blas", default="sah", choices=["sah", "lbvh"], help="BLAS builder: reference CPU SAH or the device LBVH")
     args = ap.parse_args()
     from lupinpathtracer_amd import api
     from tests import util
     ctx = api.Context(0)
     t = time.perf_counter()
-    scene, cams = util.load_scene(args.scene, ctx)
+    if args.blas == "sah":
+        scene, cams = util.load_scene(args.scene, ctx)
+    else:
+        from lupinpathtracer_amd import loader
+        if args.scene.startswith("bistro_class"):
+            scene, cams = loader.build_scene_bistro_class(ctx, util.SHARED, blas_builder="lbvh")
+        else:
+            scene, cams = loader.load_scene_yoctogl_v24(os.path.join(util.SCENES, args.scene, args.scene + ".json"), ctx,
+                                                        asset_dirs=[util.SHARED], blas_builder="lbvh")
     load_s = time.perf_counter() - t
     cam = cams[args.cam]
     params = api.CameraParams(**{**cam.params.__dict__, "aspect": args.width / args.height})
@@ -61,7 +70,7 @@ def main():
     print(json.dumps({"scene": args.scene, "camera": args.cam, "width": args.width, "height": args.height, "bounces": args.bounces,
                       "spp_per_step": args.spp, "steps": args.steps, "type": args.type, "Msamples_per_s": st["path_bounces"] / dt / 1e6,
                       "Mpaths_per_s": st["paths"] / dt / 1e6, "ms_per_step": dt / args.steps * 1e3,
-                      "bounces_per_path": st["path_bounces"] / st["paths"], "scene_stats": scene.stats, "load_and_build_s": load_s,
+                      "bounces_per_path": st["path_bounces"] / st["paths"], "scene_stats": scene.stats, "blas_builder": args.blas, "load_and_build_s": load_s,
                       "kernel_ms_2steps": {"extend": kst["extend_ms"], "shade": kst["shade_ms"], "total": kst["total_ms"]}}))
 
 
