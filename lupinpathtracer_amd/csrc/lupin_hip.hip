@@ -206,6 +206,9 @@ __global__ void __launch_bounds__(LP_BLOCK) k_begin(FrameParams fp, PathBuffers 
 #ifndef LP_SHADE_WAVES
 #define LP_SHADE_WAVES 3
 #endif
+#ifndef LP_MIS_SHADE_WAVES
+#define LP_MIS_SHADE_WAVES 2
+#endif
 // dynamic LDS layout of the stage kernels: [traversal stacks: stack_entries * LP_BLOCK words][geometry blob, if staged]
 template <bool LDSGEO> struct GeoOf { typedef GeoGlobal type; };
 template <> struct GeoOf<true> { typedef GeoLds type; };
@@ -812,7 +815,7 @@ __device__ __forceinline__ bool shade_path(const Geo &geo, const SceneDev &sc, u
 }
 
 template <int TYPE, bool LDSGEO>
-__global__ void __attribute__((amdgpu_waves_per_eu(TYPE == 1 ? 1 : LP_SHADE_WAVES, 8))) __launch_bounds__(LP_BLOCK) k_shade(SceneDev sc, FrameParams fp, PathBuffers pb, uint32_t iter,
+__global__ void __attribute__((amdgpu_waves_per_eu(TYPE == 1 ? LP_MIS_SHADE_WAVES : LP_SHADE_WAVES, 8))) __launch_bounds__(LP_BLOCK) k_shade(SceneDev sc, FrameParams fp, PathBuffers pb, uint32_t iter,
                                                     unsigned long long *shard_stats, uint32_t stack_words)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
