@@ -60,7 +60,8 @@ struct PathBuffers
     float4 *sh_d0;      // ray 0 direction | scalar 0
     float4 *sh_f0;      // ray 0 factor = weight * bsdfcos
     float4 *sh_d1;      // ray 1 direction | scalar 1
-    float4 *sh_f1;      // ray 1 factor
+    float4 *sh_f1;      // ray 1 factor (.w: triangle of the pre-traced hit, see sh_hit1)
+    float4 *sh_hit1;    // large scenes trace the shadow rays in the persistent kernel: hit record of ray 1 (ray 0 -> next_hit)
     // Live-path queues, sharded: one global counter per iteration would serialise every wave's append on a
     // single L2 atomic (~88 per microsecond chip-wide -- measured: 186 us per 1M-path iteration, more than the
     // shading itself).  Each of LP_SHARDS shards owns a fixed segment of the queue and its own counter; block b
@@ -294,7 +295,11 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launc
 #define LP_REFILL_MIN 16
 #endif
 
-template <int TYPE, bool LDSGEO>
+// MODE 0: the integrator's closest-hit queries (one per queue entry, stochastic alpha skipping).
+// MODE 1: the shadow rays k_shade recorded for MIS / Direct (two jobs per queue entry, plain closest hit); their hits go
+//         to next_hit / next_tri (MIS ray 0, which doubles as the next vertex) or sh_hit1 / sh_f1.w, and
+//         k_shadow<.., PRETRACED> folds them into the radiance.
+template <int TYPE, bool LDSGEO, int MODE>
 __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, FrameParams fp, PathBuffers pb, uint32_t iter,
                                                                 unsigned long long *shard_stats, uint32_t refill_min, uint32_t stack_words, uint32_t nsteps)
 {
@@ -304,13 +309,13 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, Fra
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t *counts = pb.counts + (size_t)iter * LP_SHARDS;
     const uint32_t *queue = pb.queue[iter & 1];
-    if (blockIdx.x == 0) { const uint32_t c = counts[tid]; if (c) shard_stats[tid * 2 + 0] += c; }   // one writer per shard per launch
+    if (MODE == 0 && blockIdx.x == 0) { const uint32_t c = counts[tid]; if (c) shard_stats[tid * 2 + 0] += c; }   // one writer per shard per launch
 
     // this wave's share of the work
     const uint32_t wave = blockIdx.x * (LP_BLOCK / 64) + tid / 64;         // wave-uniform
     const uint32_t wps = (gridDim.x * (LP_BLOCK / 64)) / LP_SHARDS;         // waves per shard (grid is a multiple of 64 blocks)
     const uint32_t shard = wave % LP_SHARDS, j = wave / LP_SHARDS;
-    const uint32_t cnt = counts[shard];
+    const uint32_t cnt = counts[shard] * (MODE == 1 ? 2u : 1u);   // jobs
     const uint32_t full_chunks = cnt / 64u;
     uint32_t n_mine = (full_chunks > j) ? ((full_chunks - j - 1u) / wps + 1u) * 64u : 0u;
     if ((cnt % 64u) && (full_chunks % wps) == j) n_mine += cnt % 64u;       // the partial last chunk
@@ -323,7 +328,7 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, Fra
 
     // per-lane ray + traversal state
     bool active = false;
-    uint32_t slot = 0, rng = 0, rng_in = 0, alpha_k = 0;
+    uint32_t slot = 0, rng = 0, rng_in = 0, alpha_k = 0, ray_k = 0;
     float total_dst = 0.0f;
     f3 o = splat(0.0f), d = splat(0.0f), inv_d = splat(0.0f);
     f3 co = o, cd = d, cinv = inv_d;
@@ -369,7 +374,7 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, Fra
             const uint32_t pos = next_pos + my_rank;
             const size_t q_index = shard_base + (size_t)((pos / 64u) * wps + j) * 64u + pos % 64u;
             next_pos += take;
-            if (got)
+            if (got && MODE == 0)
             {
                 slot = queue[q_index];
                 const float4 orr = pb.ori_rng[slot];
@@ -391,6 +396,21 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, Fra
                     rng = rng_in = __float_as_uint(orr.w);
                     total_dst = 0.0f;
                     alpha_k = 0;
+                    start_traversal();
+                    active = true;
+                }
+            }
+            if (got && MODE == 1)
+            {
+                const size_t job = q_index - shard_base;
+                slot = queue[shard_base + (job >> 1)];
+                ray_k = (uint32_t)(job & 1u);
+                const float4 so = pb.sh_org[slot];
+                if (__float_as_uint(so.w) & (1u << ray_k))
+                {
+                    const float4 dd = ray_k ? pb.sh_d1[slot] : pb.sh_d0[slot];
+                    o = mk3(so.x, so.y, so.z);
+                    d = mk3(dd.x, dd.y, dd.z);
                     start_traversal();
                     active = true;
                 }
@@ -455,7 +475,15 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, Fra
         else
         {
             // ---- F: end of a traversal = one iteration of ray_skip_alpha_stochastically (bvh_custom.wgsl:154-180) ----
-            if (isF)
+            if (isF && MODE == 1)
+            {
+                const bool hit = best.t != LP_F32_MAX;
+                const float4 rec = make_float4(hit ? best.t : 0.0f, hit ? best.u : 0.0f, hit ? best.v : 0.0f, __uint_as_float(hit ? best.inst : HIT_MISS));
+                if (TYPE == LUPIN_PATHTRACE_MIS && ray_k == 0) { pb.next_hit[slot] = rec; pb.next_tri[slot] = best.tri; }
+                else { pb.sh_hit1[slot] = rec; pb.sh_f1[slot].w = __uint_as_float(best.tri); }
+                active = false;
+            }
+            if (isF && MODE == 0)
             {
                 const bool hit = best.t != LP_F32_MAX;
                 bool again = false;
@@ -880,7 +908,7 @@ __device__ __forceinline__ f3 surface_emission(const SceneDev &sc, const Surface
 // Shadow-ray stage of the MIS and Direct integrators: traces the rays k_shade recorded (plain closest hit, no alpha
 // skipping -- pathtracer.wgsl:834,1126), adds their terms to the path radiance in the reference's order, keeps the
 // BSDF-sampled hit as MIS `next_intersection`, and finishes paths that ended at this vertex.
-template <int TYPE, bool LDSGEO>
+template <int TYPE, bool LDSGEO, bool PRETRACED>
 __global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launch_bounds__(LP_BLOCK) k_shadow(SceneDev sc, FrameParams fp, PathBuffers pb, uint32_t iter,
                                                      uint32_t stack_words)
 {
@@ -906,9 +934,18 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launc
             const float4 dd = k ? pb.sh_d1[slot] : pb.sh_d0[slot];
             const float4 ff = k ? pb.sh_f1[slot] : pb.sh_f0[slot];
             const f3 dir = mk3(dd.x, dd.y, dd.z);
-            const Closest c = scene_closest(geo, sc, lds_stack, org, dir, eps);
+            Closest c;
+            if (PRETRACED)   // k_extend_persistent<.., 1> traced the ray
+            {
+                const bool first = (TYPE == LUPIN_PATHTRACE_MIS && k == 0);
+                const float4 rec = first ? pb.next_hit[slot] : pb.sh_hit1[slot];
+                c.inst = __float_as_uint(rec.w);
+                c.t = c.inst != HIT_MISS ? rec.x : LP_F32_MAX; c.u = rec.y; c.v = rec.z;
+                c.tri = first ? pb.next_tri[slot] : __float_as_uint(ff.w);
+            }
+            else c = scene_closest(geo, sc, lds_stack, org, dir, eps);
             const bool hit = c.t != LP_F32_MAX;
-            if (TYPE == LUPIN_PATHTRACE_MIS && k == 0)
+            if (!PRETRACED && TYPE == LUPIN_PATHTRACE_MIS && k == 0)
             {
                 pb.next_hit[slot] = make_float4(hit ? c.t : 0.0f, hit ? c.u : 0.0f, hit ? c.v : 0.0f, __uint_as_float(hit ? c.inst : HIT_MISS));
                 pb.next_tri[slot] = c.tri;
@@ -1351,6 +1388,7 @@ struct LupinContext
     uint32_t num_cus = 256;
     int blocks_per_cu_override = 0; // LUPIN_EXTEND_BLOCKS_PER_CU
     uint32_t refill_min = LP_REFILL_MIN;   // LUPIN_REFILL_MIN
+    bool persistent_shadow = true;          // LUPIN_SHADOW=simple: MIS / Direct shadow rays stay in k_shadow even on large scenes
     uint32_t node_steps = 4;               // LUPIN_NODE_STEPS: node visits per scheduling round of k_extend_persistent
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_extend, ev_shade, ev_total;
     std::vector<hipEvent_t> ev_pool;
@@ -1422,10 +1460,10 @@ static int ensure_path_buffers(LupinContext *ctx0, Lane *ctx, uint64_t slots, ui
         void **ptrs[] = {(void **)&pb.ori_rng, (void **)&pb.dir_meta, (void **)&pb.weight, (void **)&pb.radiance, (void **)&pb.color,
                          (void **)&pb.hit, (void **)&pb.hit_tri, (void **)&pb.vol0, (void **)&pb.vol1, (void **)&pb.next_hit,
                          (void **)&pb.next_tri, (void **)&pb.queue[0], (void **)&pb.queue[1],
-                         (void **)&pb.sh_org, (void **)&pb.sh_d0, (void **)&pb.sh_f0, (void **)&pb.sh_d1, (void **)&pb.sh_f1};
-        size_t elem[] = {16, 16, 16, 16, 16, 16, 4, 16, 16, 16, 4, 4, 4, 16, 16, 16, 16, 16};
+                         (void **)&pb.sh_org, (void **)&pb.sh_d0, (void **)&pb.sh_f0, (void **)&pb.sh_d1, (void **)&pb.sh_f1, (void **)&pb.sh_hit1};
+        size_t elem[] = {16, 16, 16, 16, 16, 16, 4, 16, 16, 16, 4, 4, 4, 16, 16, 16, 16, 16, 16};
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        for (int k = 0; k < 18; k++)
+        for (int k = 0; k < 19; k++)
         {
             if (*ptrs[k]) { hipFree(*ptrs[k]); *ptrs[k] = nullptr; }
             HIP_TRY(hipMalloc(ptrs[k], (size_t)slots * elem[k]));
@@ -1472,26 +1510,39 @@ static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *sc
     hipStream_t st = ln->stream;
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     if (ctx->timing) { e0 = get_event(ctx); e1 = get_event(ctx); e2 = get_event(ctx); hipEventRecord(e0, st); }
-    if (ctx->persistent_extend == 1 || (ctx->persistent_extend == 2 && !LDSGEO))
+    const bool persistent = ctx->persistent_extend == 1 || (ctx->persistent_extend == 2 && !LDSGEO);
+    uint32_t pblocks = 0;
+    if (persistent)
     {
         // as many blocks as the device keeps resident with this scene's traversal-stack size (whole waves per shard)
-        uint32_t &pblocks = const_cast<LupinScene *>(scene)->persistent_blocks[TYPE];
-        if (pblocks == 0)
+        uint32_t &cached = const_cast<LupinScene *>(scene)->persistent_blocks[TYPE];
+        if (cached == 0)
         {
             int per_cu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extend_persistent<TYPE, LDSGEO>, LP_BLOCK, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extend_persistent<TYPE, LDSGEO, 0>, LP_BLOCK, lds) != hipSuccess || per_cu < 1) per_cu = 1;
             if (ctx->blocks_per_cu_override > 0) per_cu = ctx->blocks_per_cu_override;
-            pblocks = std::max(64u, ctx->num_cus * (uint32_t)per_cu / 64u * 64u);
+            cached = std::max(64u, ctx->num_cus * (uint32_t)per_cu / 64u * 64u);
         }
-        hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO>), dim3(pblocks), dim3(LP_BLOCK), lds, st,
+        pblocks = cached;
+        hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, 0>), dim3(pblocks), dim3(LP_BLOCK), lds, st,
                            scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words, ctx->node_steps);
     }
     else
         hipLaunchKernelGGL((k_extend<TYPE, LDSGEO>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
     if (ctx->timing) hipEventRecord(e1, st);
     hipLaunchKernelGGL((k_shade<TYPE, LDSGEO>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
-    if (TYPE == LUPIN_PATHTRACE_MIS || TYPE == LUPIN_PATHTRACE_DIRECT)   // shadow rays + path finish (booked with "shade" in the timing)
-        hipLaunchKernelGGL((k_shadow<TYPE, LDSGEO>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, stack_words);
+    if constexpr (TYPE == LUPIN_PATHTRACE_MIS || TYPE == LUPIN_PATHTRACE_DIRECT)   // shadow rays + path finish (booked with "shade" in the timing)
+    {
+        if (persistent && ctx->persistent_shadow)
+        {
+            // large scenes: the shadow rays go through the phase-scheduled persistent tracer as well, then a light finish pass
+            hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, 1>), dim3(pblocks), dim3(LP_BLOCK), lds, st,
+                               scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words, ctx->node_steps);
+            hipLaunchKernelGGL((k_shadow<TYPE, LDSGEO, true>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, stack_words);
+        }
+        else
+            hipLaunchKernelGGL((k_shadow<TYPE, LDSGEO, false>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, stack_words);
+    }
     if (ctx->timing)
     {
         hipEventRecord(e2, st);
@@ -1575,6 +1626,8 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
         if (bpc) ctx->blocks_per_cu_override = std::max(0, atoi(bpc));
         ctx->num_cus = (uint32_t)prop.multiProcessorCount;
     }
+    const char *shd = getenv("LUPIN_SHADOW");
+    if (shd && strcmp(shd, "simple") == 0) ctx->persistent_shadow = false;
     const char *ns = getenv("LUPIN_NODE_STEPS");
     if (ns) ctx->node_steps = (uint32_t)std::min(16, std::max(1, atoi(ns)));
     const char *rm = getenv("LUPIN_REFILL_MIN");
@@ -1593,7 +1646,7 @@ void lupin_hip_destroy_context(LupinContext *ctx)
         PathBuffers &pb = ctx->lanes[k].pb;
         void *ptrs[] = {pb.ori_rng, pb.dir_meta, pb.weight, pb.radiance, pb.color, pb.hit, pb.hit_tri, pb.vol0, pb.vol1,
                         pb.next_hit, pb.next_tri, pb.queue[0], pb.queue[1], pb.counts, ctx->lanes[k].stat_counters,
-                        pb.sh_org, pb.sh_d0, pb.sh_f0, pb.sh_d1, pb.sh_f1};
+                        pb.sh_org, pb.sh_d0, pb.sh_f0, pb.sh_d1, pb.sh_f1, pb.sh_hit1};
         for (void *p : ptrs) if (p) hipFree(p);
         if (ctx->lanes[k].done) hipEventDestroy(ctx->lanes[k].done);
     }
