@@ -72,7 +72,10 @@ struct PathBuffers
     uint32_t shard_cap;   // slots per shard (multiple of LP_BLOCK)
 };
 
-constexpr uint32_t LP_SHARDS = 256;
+#ifndef LP_NUM_SHARDS
+#define LP_NUM_SHARDS 256
+#endif
+constexpr uint32_t LP_SHARDS = LP_NUM_SHARDS;
 
 struct FrameParams
 {
@@ -305,11 +308,11 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, Fra
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     const auto geo = make_geo<LDSGEO>(sc, lds_stack, stack_words);
-    static_assert(LP_SHARDS == LP_BLOCK, "block 0 books one shard per thread");
+    static_assert(LP_SHARDS <= LP_BLOCK && 256 % LP_SHARDS == 0, "block 0 books one shard per thread; 64-block grids hold whole waves per shard");
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t *counts = pb.counts + (size_t)iter * LP_SHARDS;
     const uint32_t *queue = pb.queue[iter & 1];
-    if (MODE == 0 && blockIdx.x == 0) { const uint32_t c = counts[tid]; if (c) shard_stats[tid * 2 + 0] += c; }   // one writer per shard per launch
+    if (MODE == 0 && blockIdx.x == 0 && tid < LP_SHARDS) { const uint32_t c = counts[tid]; if (c) shard_stats[tid * 2 + 0] += c; }   // one writer per shard per launch
 
     // this wave's share of the work
     const uint32_t wave = blockIdx.x * (LP_BLOCK / 64) + tid / 64;         // wave-uniform
