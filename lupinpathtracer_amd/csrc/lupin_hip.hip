@@ -68,7 +68,6 @@ struct PathBuffers
     // always reads and appends shard b % LP_SHARDS, so a shard never grows beyond its initial size.
     uint32_t *queue[2];   // [parity][shard * shard_cap + i]
     uint32_t *counts;     // counts[k * LP_SHARDS + s] = live paths of shard s entering iteration k
-    uint32_t *heads;      // heads[k * LP_SHARDS + s]  = next unclaimed queue entry (persistent extend kernel)
     uint32_t shard_cap;   // slots per shard (multiple of LP_BLOCK)
 };
 
@@ -1478,9 +1477,7 @@ static int ensure_path_buffers(LupinContext *ctx0, Lane *ctx, uint64_t slots, ui
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->pb.counts) hipFree(ctx->pb.counts);
         ctx->pb.counts = nullptr;
-        // counts and heads live in one allocation so that a single memset clears both
-        HIP_TRY(hipMalloc((void **)&ctx->pb.counts, (size_t)(iterations + 2) * LP_SHARDS * sizeof(uint32_t) * 2));
-        ctx->pb.heads = ctx->pb.counts + (size_t)(iterations + 2) * LP_SHARDS;
+        HIP_TRY(hipMalloc((void **)&ctx->pb.counts, (size_t)(iterations + 2) * LP_SHARDS * sizeof(uint32_t)));
         ctx->counts_capacity = iterations + 2;
     }
     return LUPIN_OK;
@@ -2293,7 +2290,7 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (ctx->timing) { t0 = get_event(ctx); t1 = get_event(ctx); hipEventRecord(t0, st); }
 
-    HIP_TRY(hipMemsetAsync(ln->pb.counts, 0, (size_t)ln->counts_capacity * LP_SHARDS * sizeof(uint32_t) * 2, st));
+    HIP_TRY(hipMemsetAsync(ln->pb.counts, 0, (size_t)ln->counts_capacity * LP_SHARDS * sizeof(uint32_t), st));
     hipLaunchKernelGGL(k_begin, dim3(blocks), dim3(LP_BLOCK), 0, st, fp, ln->pb, n);
     for (uint32_t it = 0; it < iterations; it++)
     {
