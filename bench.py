@@ -175,6 +175,7 @@ def main():
 
     # ---- CPU baseline (rank 0, N = 1): one full step of the same workload on the oracle ----
     cpu_baseline = None
+    parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
         host_scene, host_cams = loader.build_scene_cornell_box(None)
@@ -183,8 +184,16 @@ def main():
         side = args.size
         oracle.pathtrace(host_scene, 64, 64, hc.params, hc.transform, args.bounces, 1)   # page the library in
         c0 = time.perf_counter()
-        _, cnt = oracle.pathtrace(host_scene, side, side, hc.params, hc.transform, args.bounces, args.spp)
+        cpu_img, cnt = oracle.pathtrace(host_scene, side, side, hc.params, hc.transform, args.bounces, args.spp)
         cdt = time.perf_counter() - c0
+        # the same frame (accum_counter 0) through the HIP path: BASELINE's RMSE figure, against the restatement
+        chk = api.Texture(ctx, side, side)
+        api.pathtrace_scene(ctx, res, scene, chk, ptype, api.PathtraceDesc(camera_params=hc.params, camera_transform=hc.transform))
+        gpu_img = chk.download()
+        diff = gpu_img[..., :3].astype(np.float32) - cpu_img[..., :3].astype(np.float32)
+        parity = {"rmse_vs_cpu_restatement": float(np.sqrt((diff ** 2).mean())),
+                  "differing_f16_words": int((gpu_img.view(np.uint16) != cpu_img.view(np.uint16)).sum()),
+                  "sample": f"frame 0 of the workload, {side}x{side}, {args.spp} spp"}
         cpu_baseline = {"value": cnt["path_bounces"] / cdt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
                         "sample": f"1 step: cornellbox {side}x{side}, {args.bounces} bounces, {args.spp} spp "
                                   f"({cnt['path_bounces']} path-bounces, {cdt:.2f} s, OpenMP over rows)"}
@@ -203,7 +212,7 @@ def main():
                        "sharding": "single dispatch" if world == 1 else f"tile-sharded, tile {args.tile_size * 4}px, round-robin, RCCL all-gather at readback"},
             "Mpaths_per_s": total_paths / elapsed / 1e6,
             "path_bounces": total_units,
-            "roofline": roofline, "kernel_ms": kernel_ms, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "kernel_ms": kernel_ms, "cpu_baseline": cpu_baseline, "parity": parity,
         }
         print(json.dumps(line))
     if dist is not None:
