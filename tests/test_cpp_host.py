@@ -52,3 +52,30 @@ def test_example1_matches_python_host(gpu_ctx, example1, tmp_path):
     tex = api.Texture(gpu_ctx, 64, 64)
     tex.upload(img)
     assert np.array_equal(ppm, api.tonemap_and_fit_aspect(gpu_ctx, tex, 64, 64)[..., :3])
+
+
+@pytest.fixture(scope="module")
+def render_scene(built):
+    exe = os.path.join(ROOT, "examples", "render_scene")
+    lib_dir = os.path.join(ROOT, "lupinpathtracer_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "render_scene.cpp"),
+                           "-L" + lib_dir, "-llupin_hip", "-L/opt/rocm/lib", "-lz", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    return exe
+
+
+@pytest.mark.gpu
+def test_render_scene_cpp_loader_matches_python_host(gpu_ctx, render_scene, tmp_path):
+    """The whole C++ host chain (lupin_loader.hpp -> lupin.hpp -> C ABI) on a textured fixture scene with an HDR
+    environment gives the image the Python host gives."""
+    from lupinpathtracer_amd import api, loader
+    from tests import util
+    name, cam_i, W = "features1", 1, 192
+    out = str(tmp_path / "render.hdr")
+    subprocess.check_call([render_scene, os.path.join(util.SCENES, name, name + ".json"), str(cam_i), str(W), "3", "4", out, "", util.SHARED])
+    cpp = loader.read_hdr(out)
+    scene, cams = util.load_scene(name, gpu_ctx)
+    H = int(np.float32(W) / np.float32(cams[cam_i].params.aspect))
+    img = util.gpu_accumulate(gpu_ctx, scene, cams[cam_i], W, H, frames=3, spp=4, advanced=api.AdvancedParams(max_radiance=10.0))
+    ref_path = str(tmp_path / "ref.hdr")
+    loader.save_texture(ref_path, img)
+    assert np.array_equal(cpp, loader.read_hdr(ref_path))
