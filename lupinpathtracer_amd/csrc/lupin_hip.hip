@@ -174,8 +174,13 @@ __device__ __forceinline__ void queue_append(bool alive, uint32_t slot, uint32_t
 // Stage kernels
 // ------------------------------------------------------------------------------------------------
 
-__global__ void __launch_bounds__(LP_BLOCK) k_begin(FrameParams fp, PathBuffers pb, uint32_t n)
+// publishes one call's parameters to the lane's device copy (kernel arguments are captured at launch, so the host
+// struct may go out of scope)
+__global__ void k_set_params(FrameParams fp, FrameParams *dst) { *dst = fp; }
+
+__global__ void __launch_bounds__(LP_BLOCK) k_begin(const FrameParams *__restrict__ fpp, PathBuffers pb, uint32_t n)
 {
+    const FrameParams fp = *fpp;   // per-frame parameters live in device memory so that a captured graph can be replayed
     uint32_t slot = blockIdx.x * LP_BLOCK + threadIdx.x;
     uint32_t gx = 0, gy = 0;
     bool live = slot < n;
@@ -254,9 +259,10 @@ __device__ __forceinline__ void trace_alpha(const Geo &geo, const SceneDev &sc, 
 }
 
 template <int TYPE, bool LDSGEO>
-__global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launch_bounds__(LP_BLOCK) k_extend(SceneDev sc, FrameParams fp, PathBuffers pb, uint32_t iter,
+__global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launch_bounds__(LP_BLOCK) k_extend(SceneDev sc, const FrameParams *__restrict__ fpp, PathBuffers pb, uint32_t iter,
                                                      unsigned long long *shard_stats, uint32_t stack_words)
 {
+    const FrameParams fp = *fpp;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     const auto geo = make_geo<LDSGEO>(sc, lds_stack, stack_words);
     const uint32_t shard = blockIdx.x % LP_SHARDS;
@@ -302,9 +308,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launc
 //         to next_hit / next_tri (MIS ray 0, which doubles as the next vertex) or sh_hit1 / sh_f1.w, and
 //         k_shadow<.., PRETRACED> folds them into the radiance.
 template <int TYPE, bool LDSGEO, int MODE>
-__global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, FrameParams fp, PathBuffers pb, uint32_t iter,
+__global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, const FrameParams *__restrict__ fpp, PathBuffers pb, uint32_t iter,
                                                                 unsigned long long *shard_stats, uint32_t refill_min, uint32_t stack_words, uint32_t nsteps)
 {
+    const FrameParams fp = *fpp;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     const auto geo = make_geo<LDSGEO>(sc, lds_stack, stack_words);
     static_assert(LP_SHARDS <= LP_BLOCK && 256 % LP_SHARDS == 0, "block 0 books one shard per thread; 64-block grids hold whole waves per shard");
@@ -845,9 +852,10 @@ __device__ __forceinline__ bool shade_path(const Geo &geo, const SceneDev &sc, u
 }
 
 template <int TYPE, bool LDSGEO>
-__global__ void __attribute__((amdgpu_waves_per_eu(TYPE == 1 ? LP_MIS_SHADE_WAVES : LP_SHADE_WAVES, 8))) __launch_bounds__(LP_BLOCK) k_shade(SceneDev sc, FrameParams fp, PathBuffers pb, uint32_t iter,
+__global__ void __attribute__((amdgpu_waves_per_eu(TYPE == 1 ? LP_MIS_SHADE_WAVES : LP_SHADE_WAVES, 8))) __launch_bounds__(LP_BLOCK) k_shade(SceneDev sc, const FrameParams *__restrict__ fpp, PathBuffers pb, uint32_t iter,
                                                     unsigned long long *shard_stats, uint32_t stack_words)
 {
+    const FrameParams fp = *fpp;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     const auto geo = make_geo<LDSGEO>(sc, lds_stack, stack_words);
     const uint32_t shard = blockIdx.x % LP_SHARDS;
@@ -911,9 +919,10 @@ __device__ __forceinline__ f3 surface_emission(const SceneDev &sc, const Surface
 // skipping -- pathtracer.wgsl:834,1126), adds their terms to the path radiance in the reference's order, keeps the
 // BSDF-sampled hit as MIS `next_intersection`, and finishes paths that ended at this vertex.
 template <int TYPE, bool LDSGEO, bool PRETRACED>
-__global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launch_bounds__(LP_BLOCK) k_shadow(SceneDev sc, FrameParams fp, PathBuffers pb, uint32_t iter,
+__global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launch_bounds__(LP_BLOCK) k_shadow(SceneDev sc, const FrameParams *__restrict__ fpp, PathBuffers pb, uint32_t iter,
                                                      uint32_t stack_words)
 {
+    const FrameParams fp = *fpp;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     const auto geo = make_geo<LDSGEO>(sc, lds_stack, stack_words);
     const uint32_t shard = blockIdx.x % LP_SHARDS;
@@ -1372,6 +1381,18 @@ struct Lane
     unsigned long long *stat_counters = nullptr;   // per shard: [2s] path bounces, [2s+1] paths
     hipEvent_t done = nullptr;      // recorded after the last kernel of the lane's latest call
     bool used = false;
+    FrameParams *d_fp = nullptr;    // this lane's per-call parameters (k_set_params writes, the stage kernels read)
+    uint64_t pb_generation = 0;     // bumped when the path buffers are reallocated
+    // the lane's wavefront (memset + k_begin + all iterations) as a replayable graph
+    struct GraphKey
+    {
+        uint64_t scene_id = 0, pb_generation = 0;
+        uint32_t n = 0, blocks = 0, type = 0, iterations = 0, stack_words = 0, lds = 0, pblocks = 0, refill_min = 0, node_steps = 0;
+        int persistent = 0, persistent_shadow = 0, lds_geometry = 0;
+        bool operator==(const GraphKey &o) const { return memcmp(this, &o, sizeof(GraphKey)) == 0; }
+    } graph_key, seen_key;           // key of graph_exec | key of the lane's previous call
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
 };
 
 struct LupinContext
@@ -1390,6 +1411,7 @@ struct LupinContext
     uint32_t num_cus = 256;
     int blocks_per_cu_override = 0; // LUPIN_EXTEND_BLOCKS_PER_CU
     uint32_t refill_min = LP_REFILL_MIN;   // LUPIN_REFILL_MIN
+    bool use_graph = true;                  // LUPIN_GRAPH=0: launch every stage kernel individually
     bool persistent_shadow = true;          // LUPIN_SHADOW=simple: MIS / Direct shadow rays stay in k_shadow even on large scenes
     uint32_t node_steps = 4;               // LUPIN_NODE_STEPS: node visits per scheduling round of k_extend_persistent
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_extend, ev_shade, ev_total;
@@ -1424,6 +1446,7 @@ struct LupinScene
     std::vector<void *> allocations;
     uint32_t stack_entries = 1;
     uint32_t persistent_blocks[4] = {0, 0, 0, 0};   // grid of k_extend_persistent per integrator (lazy)
+    uint64_t id = 0;                                // unique per created scene (graph cache key)
     bool has_sw_bvh = false;
     bool envs_empty = true, lights_empty = true, instances_empty = true;
 };
@@ -1471,6 +1494,7 @@ static int ensure_path_buffers(LupinContext *ctx0, Lane *ctx, uint64_t slots, ui
             HIP_TRY(hipMalloc(ptrs[k], (size_t)slots * elem[k]));
         }
         ctx->capacity = slots;
+        ctx->pb_generation++;
     }
     if (iterations + 2 > ctx->counts_capacity)
     {
@@ -1479,6 +1503,7 @@ static int ensure_path_buffers(LupinContext *ctx0, Lane *ctx, uint64_t slots, ui
         ctx->pb.counts = nullptr;
         HIP_TRY(hipMalloc((void **)&ctx->pb.counts, (size_t)(iterations + 2) * LP_SHARDS * sizeof(uint32_t)));
         ctx->counts_capacity = iterations + 2;
+        ctx->pb_generation++;
     }
     return LUPIN_OK;
 }
@@ -1504,29 +1529,45 @@ static uint32_t blas_depth(const LupinBvhNode *nodes, uint32_t count)
     return best;
 }
 
+// grid of the persistent tracer: as many blocks as the device keeps resident with this scene's traversal-stack size
+// (whole waves per shard); queried once per scene and integrator, outside any stream capture
 template <int TYPE, bool LDSGEO>
-static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *scene, const FrameParams &fp, uint32_t blocks, size_t lds, uint32_t stack_words, uint32_t iter)
+static uint32_t persistent_grid_t(LupinContext *ctx, const LupinScene *scene, size_t lds)
+{
+    uint32_t &cached = const_cast<LupinScene *>(scene)->persistent_blocks[TYPE];
+    if (cached == 0)
+    {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extend_persistent<TYPE, LDSGEO, 0>, LP_BLOCK, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (ctx->blocks_per_cu_override > 0) per_cu = ctx->blocks_per_cu_override;
+        cached = std::max(64u, ctx->num_cus * (uint32_t)per_cu / 64u * 64u);
+    }
+    return cached;
+}
+static bool use_persistent(const LupinContext *ctx, bool lds_geo) { return ctx->persistent_extend == 1 || (ctx->persistent_extend == 2 && !lds_geo); }
+static uint32_t persistent_grid(LupinContext *ctx, const LupinScene *scene, uint32_t type, bool lds_geo, size_t lds)
+{
+    if (!use_persistent(ctx, lds_geo)) return 0;
+    switch (type)
+    {
+    case LUPIN_PATHTRACE_STANDARD: return lds_geo ? persistent_grid_t<LUPIN_PATHTRACE_STANDARD, true>(ctx, scene, lds) : persistent_grid_t<LUPIN_PATHTRACE_STANDARD, false>(ctx, scene, lds);
+    case LUPIN_PATHTRACE_MIS: return lds_geo ? persistent_grid_t<LUPIN_PATHTRACE_MIS, true>(ctx, scene, lds) : persistent_grid_t<LUPIN_PATHTRACE_MIS, false>(ctx, scene, lds);
+    case LUPIN_PATHTRACE_NAIVE: return lds_geo ? persistent_grid_t<LUPIN_PATHTRACE_NAIVE, true>(ctx, scene, lds) : persistent_grid_t<LUPIN_PATHTRACE_NAIVE, false>(ctx, scene, lds);
+    default: return lds_geo ? persistent_grid_t<LUPIN_PATHTRACE_DIRECT, true>(ctx, scene, lds) : persistent_grid_t<LUPIN_PATHTRACE_DIRECT, false>(ctx, scene, lds);
+    }
+}
+
+template <int TYPE, bool LDSGEO>
+static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *scene, uint32_t blocks, uint32_t pblocks, size_t lds, uint32_t stack_words, uint32_t iter)
 {
     hipStream_t st = ln->stream;
+    const FrameParams *fp = ln->d_fp;
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     if (ctx->timing) { e0 = get_event(ctx); e1 = get_event(ctx); e2 = get_event(ctx); hipEventRecord(e0, st); }
-    const bool persistent = ctx->persistent_extend == 1 || (ctx->persistent_extend == 2 && !LDSGEO);
-    uint32_t pblocks = 0;
+    const bool persistent = pblocks != 0;
     if (persistent)
-    {
-        // as many blocks as the device keeps resident with this scene's traversal-stack size (whole waves per shard)
-        uint32_t &cached = const_cast<LupinScene *>(scene)->persistent_blocks[TYPE];
-        if (cached == 0)
-        {
-            int per_cu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extend_persistent<TYPE, LDSGEO, 0>, LP_BLOCK, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-            if (ctx->blocks_per_cu_override > 0) per_cu = ctx->blocks_per_cu_override;
-            cached = std::max(64u, ctx->num_cus * (uint32_t)per_cu / 64u * 64u);
-        }
-        pblocks = cached;
         hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, 0>), dim3(pblocks), dim3(LP_BLOCK), lds, st,
                            scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words, ctx->node_steps);
-    }
     else
         hipLaunchKernelGGL((k_extend<TYPE, LDSGEO>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
     if (ctx->timing) hipEventRecord(e1, st);
@@ -1553,13 +1594,33 @@ static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *sc
 }
 
 template <int TYPE>
-static void launch_iteration(LupinContext *ctx, Lane *ln, const LupinScene *scene, const FrameParams &fp, uint32_t blocks, size_t lds, uint32_t stack_words, uint32_t iter)
+static void launch_iteration(LupinContext *ctx, Lane *ln, const LupinScene *scene, bool lds_geo, uint32_t blocks, uint32_t pblocks, size_t lds, uint32_t stack_words, uint32_t iter)
 {
-    if (scene->dev.geo_blob_words && ctx->lds_geometry) launch_iteration_t<TYPE, true>(ctx, ln, scene, fp, blocks, lds, stack_words, iter);
-    else launch_iteration_t<TYPE, false>(ctx, ln, scene, fp, blocks, lds, stack_words, iter);
+    if (lds_geo) launch_iteration_t<TYPE, true>(ctx, ln, scene, blocks, pblocks, lds, stack_words, iter);
+    else launch_iteration_t<TYPE, false>(ctx, ln, scene, blocks, pblocks, lds, stack_words, iter);
 }
 
-// Orders the primary stream after everything the second lane has been asked to do (textures, counters).
+// the lane-private part of one call: clear the queue counters, first rays, every iteration of the wavefront
+static hipError_t enqueue_wavefront(LupinContext *ctx, Lane *ln, const LupinScene *scene, uint32_t pathtrace_type, bool lds_geo, uint32_t n,
+                                    uint32_t blocks, uint32_t pblocks, size_t lds, uint32_t stack_words, uint32_t iterations)
+{
+    hipStream_t st = ln->stream;
+    hipError_t e = hipMemsetAsync(ln->pb.counts, 0, (size_t)ln->counts_capacity * LP_SHARDS * sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_begin, dim3(blocks), dim3(LP_BLOCK), 0, st, (const FrameParams *)ln->d_fp, ln->pb, n);
+    for (uint32_t it = 0; it < iterations; it++)
+    {
+        switch (pathtrace_type)
+        {
+        case LUPIN_PATHTRACE_STANDARD: launch_iteration<LUPIN_PATHTRACE_STANDARD>(ctx, ln, scene, lds_geo, blocks, pblocks, lds, stack_words, it); break;
+        case LUPIN_PATHTRACE_MIS: launch_iteration<LUPIN_PATHTRACE_MIS>(ctx, ln, scene, lds_geo, blocks, pblocks, lds, stack_words, it); break;
+        case LUPIN_PATHTRACE_NAIVE: launch_iteration<LUPIN_PATHTRACE_NAIVE>(ctx, ln, scene, lds_geo, blocks, pblocks, lds, stack_words, it); break;
+        default: launch_iteration<LUPIN_PATHTRACE_DIRECT>(ctx, ln, scene, lds_geo, blocks, pblocks, lds, stack_words, it); break;
+        }
+    }
+    return hipSuccess;
+}
+
 // The resolves form a chain (each waits for the previous call's), so the latest call's event covers all lanes' texture writes.
 static void join_primary(LupinContext *ctx)
 {
@@ -1608,6 +1669,7 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
         Lane &ln = ctx->lanes[k];
         e = hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ln.done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipMalloc((void **)&ln.d_fp, sizeof(FrameParams));
         if (e == hipSuccess) e = hipMalloc((void **)&ln.stat_counters, 2 * LP_SHARDS * sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMemsetAsync(ln.stat_counters, 0, 2 * LP_SHARDS * sizeof(unsigned long long), ln.stream);
     }
@@ -1626,6 +1688,8 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
         if (bpc) ctx->blocks_per_cu_override = std::max(0, atoi(bpc));
         ctx->num_cus = (uint32_t)prop.multiProcessorCount;
     }
+    const char *gr = getenv("LUPIN_GRAPH");
+    if (gr && strcmp(gr, "0") == 0) ctx->use_graph = false;
     const char *shd = getenv("LUPIN_SHADOW");
     if (shd && strcmp(shd, "simple") == 0) ctx->persistent_shadow = false;
     const char *ns = getenv("LUPIN_NODE_STEPS");
@@ -1649,6 +1713,9 @@ void lupin_hip_destroy_context(LupinContext *ctx)
                         pb.sh_org, pb.sh_d0, pb.sh_f0, pb.sh_d1, pb.sh_f1, pb.sh_hit1};
         for (void *p : ptrs) if (p) hipFree(p);
         if (ctx->lanes[k].done) hipEventDestroy(ctx->lanes[k].done);
+        if (ctx->lanes[k].graph_exec) hipGraphExecDestroy(ctx->lanes[k].graph_exec);
+        if (ctx->lanes[k].graph) hipGraphDestroy(ctx->lanes[k].graph);
+        if (ctx->lanes[k].d_fp) hipFree(ctx->lanes[k].d_fp);
     }
     if (ctx->marker) hipEventDestroy(ctx->marker);
     for (auto &pr : ctx->ev_extend) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
@@ -2049,6 +2116,8 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
     { const char *ss = getenv("LUPIN_SORT_SHADE"); if (ss) dv.sort_shade = strcmp(ss, "0") != 0; }
     dv.geo_blob_words = (uint32_t)geo_blob.size();
     dv.geo_off_blas = off_blas; dv.geo_off_tris = off_tris; dv.geo_off_inst = off_inst;
+    static uint64_t next_scene_id = 1;
+    sc->id = next_scene_id++;
     hipError_t e = hipStreamSynchronize(ctx->stream);   // host vectors go out of scope
     if (e != hipSuccess) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_HIP, hipGetErrorString(e)); }
     *out_scene = sc;
@@ -2290,18 +2359,45 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (ctx->timing) { t0 = get_event(ctx); t1 = get_event(ctx); hipEventRecord(t0, st); }
 
-    HIP_TRY(hipMemsetAsync(ln->pb.counts, 0, (size_t)ln->counts_capacity * LP_SHARDS * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(k_begin, dim3(blocks), dim3(LP_BLOCK), 0, st, fp, ln->pb, n);
-    for (uint32_t it = 0; it < iterations; it++)
+    const uint32_t pblocks = persistent_grid(ctx, scene, pathtrace_type, lds_geo, lds);
+    hipLaunchKernelGGL(k_set_params, dim3(1), dim3(1), 0, st, fp, ln->d_fp);
+    if (ctx->use_graph && !ctx->timing)
     {
-        switch (pathtrace_type)
+        // Everything between k_set_params and the resolve depends on the call only through *d_fp, so it is captured once per
+        // (scene, dispatch size, integrator, buffers) and replayed: one graph launch instead of 2-4 launches per iteration.
+        Lane::GraphKey key;
+        key.scene_id = scene->id; key.pb_generation = ln->pb_generation; key.n = n; key.blocks = blocks; key.type = pathtrace_type;
+        key.iterations = iterations; key.stack_words = stack_words; key.lds = (uint32_t)lds; key.pblocks = pblocks;
+        key.refill_min = ctx->refill_min; key.node_steps = ctx->node_steps; key.persistent = ctx->persistent_extend;
+        key.persistent_shadow = ctx->persistent_shadow ? 1 : 0; key.lds_geometry = lds_geo ? 1 : 0;
+        const bool have = ln->graph_exec && key == ln->graph_key;
+        if (!have && !(key == ln->seen_key))
         {
-        case LUPIN_PATHTRACE_STANDARD: launch_iteration<LUPIN_PATHTRACE_STANDARD>(ctx, ln, scene, fp, blocks, lds, stack_words, it); break;
-        case LUPIN_PATHTRACE_MIS: launch_iteration<LUPIN_PATHTRACE_MIS>(ctx, ln, scene, fp, blocks, lds, stack_words, it); break;
-        case LUPIN_PATHTRACE_NAIVE: launch_iteration<LUPIN_PATHTRACE_NAIVE>(ctx, ln, scene, fp, blocks, lds, stack_words, it); break;
-        default: launch_iteration<LUPIN_PATHTRACE_DIRECT>(ctx, ln, scene, fp, blocks, lds, stack_words, it); break;
+            // first call of this shape on the lane (or shapes alternate, e.g. edge tiles): capturing costs about a
+            // millisecond, so launch directly and capture only if the shape repeats
+            ln->seen_key = key;
+            HIP_TRY(enqueue_wavefront(ctx, ln, scene, pathtrace_type, lds_geo, n, blocks, pblocks, lds, stack_words, iterations));
+        }
+        else
+        {
+            if (!have)
+            {
+                if (ln->graph_exec) { hipGraphExecDestroy(ln->graph_exec); ln->graph_exec = nullptr; }
+                if (ln->graph) { hipGraphDestroy(ln->graph); ln->graph = nullptr; }
+                HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+                hipError_t ce = enqueue_wavefront(ctx, ln, scene, pathtrace_type, lds_geo, n, blocks, pblocks, lds, stack_words, iterations);
+                hipError_t ee = hipStreamEndCapture(st, &ln->graph);
+                if (ce != hipSuccess || ee != hipSuccess) return fail(LUPIN_ERR_HIP, std::string("graph capture: ") + hipGetErrorString(ce != hipSuccess ? ce : ee));
+                HIP_TRY(hipGraphInstantiate(&ln->graph_exec, ln->graph, nullptr, nullptr, 0));
+                ln->graph_key = key;
+            }
+            else ctx->extend_launches += iterations;
+            ln->seen_key = key;
+            HIP_TRY(hipGraphLaunch(ln->graph_exec, st));
         }
     }
+    else
+        HIP_TRY(enqueue_wavefront(ctx, ln, scene, pathtrace_type, lds_geo, n, blocks, pblocks, lds, stack_words, iterations));
     // The frames meet here: the resolve reads prev_frame and overwrites render_target, so it is ordered after everything
     // enqueued so far on the other lane (the previous call's resolve) and, for lane 1, on the primary stream (texture
     // uploads / copies).  The path state itself is private to the lane.
