@@ -313,7 +313,10 @@ const char *lupin_hip_last_error(void);
 /* number of visible HIP devices; 0 when none (never initialises a context) */
 int lupin_hip_device_count(void);
 
-/* wgpu device/queue acquisition (wgpu_utils.rs:20-120, renderer.rs:307-330) -> one HIP device + stream */
+/* wgpu device/queue acquisition (wgpu_utils.rs:20-120, renderer.rs:307-330) -> one HIP device + its streams.
+ * Like a wgpu queue, the context orders work in call order: consecutive pathtrace_scene calls may overlap on the
+ * device (they run on alternating internal streams), but each call sees the textures exactly as the calls before it
+ * left them; uploads, downloads, copies and lupin_hip_sync wait for everything submitted earlier. */
 int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx);
 void lupin_hip_destroy_context(LupinContext *ctx);
 /* device.poll(wait_indefinitely) (loader.rs:1692,1825) */
@@ -359,7 +362,8 @@ int lupin_hip_dbuf_resize(LupinDoubleBufferedTexture *t, uint32_t width, uint32_
 /* lp::get_num_tiles (renderer.rs:675-681) */
 uint32_t lupin_hip_get_num_tiles(uint32_t tile_size, uint32_t width, uint32_t height);
 
-/* lp::pathtrace_scene (renderer.rs:768-842) */
+/* lp::pathtrace_scene (renderer.rs:768-842): enqueues one accumulation frame (or one tile of it) and returns, like
+ * queue.submit (:841).  render_target must differ from accum_params->prev_frame (:754-755). */
 int lupin_hip_pathtrace_scene(LupinContext *ctx, const LupinPathtraceResources *res,
                               const LupinScene *scene, LupinTexture *render_target,
                               uint32_t pathtrace_type, const LupinPathtraceDesc *desc);
