@@ -606,17 +606,21 @@ LP_FN float surface_opacity(const SceneDev &sc, const Surface &s)
 }
 
 // get_material_point (pathtracer.wgsl:1265-1342)
+// SIMPLE: the scene is known (at upload) to hold only matte materials without texture references, so the material type
+// is a constant and no texture is consulted -- same values, far less code in the kernel that inlines this.
+template <bool SIMPLE = false>
 LP_FN MatPoint material_point(const SceneDev &sc, const Surface &s)
 {
     const LupinMaterial m = sc.materials[s.in.mat_idx];
     MatPoint r;
     r.type = m.mat_type;
+    if (SIMPLE) r.type = LUPIN_MAT_MATTE;   // a compile-time constant: the BSDF switches fold to the matte lobes
 
     float4 color_s = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
     f3 emission_s = splat(1.0f);
     float rough_s = 1.0f, metal_s = 1.0f;
     f3 scatter_s = splat(1.0f);
-    if (s.mesh.texcoords_base != LUPIN_SENTINEL_IDX)
+    if (!SIMPLE && s.mesh.texcoords_base != LUPIN_SENTINEL_IDX)
     {
         float tu, tv;
         interp_texcoords(sc, s, tu, tv);

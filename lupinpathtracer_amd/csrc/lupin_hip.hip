@@ -214,6 +214,9 @@ __global__ void __launch_bounds__(LP_BLOCK) k_begin(const FrameParams *__restric
 #ifndef LP_SHADE_WAVES
 #define LP_SHADE_WAVES 3
 #endif
+#ifndef LP_SIMPLE_SHADE_WAVES
+#define LP_SIMPLE_SHADE_WAVES 4
+#endif
 #ifndef LP_MIS_SHADE_WAVES
 #define LP_MIS_SHADE_WAVES 2
 #endif
@@ -234,7 +237,7 @@ __device__ __forceinline__ GeoLds make_geo<true>(const SceneDev &sc, uint32_t *l
 
 // One closest-hit query of the integrator loop, with stochastic alpha skipping (bvh_custom.wgsl:154-180).
 // Returns the hit record (dst accumulated over skipped surfaces | u | v | instance or HIT_MISS) and the triangle.
-template <typename Geo>
+template <typename Geo, bool OPAQUE = false>   // OPAQUE: no instance of the scene can have opacity != 1 (LupinScene::all_opaque)
 __device__ __forceinline__ void trace_alpha(const Geo &geo, const SceneDev &sc, uint32_t *stack, f3 o, f3 d, uint32_t &rng, float eps,
                                             float4 &hitrec, uint32_t &hit_tri)
 {
@@ -248,7 +251,7 @@ __device__ __forceinline__ void trace_alpha(const Geo &geo, const SceneDev &sc, 
         hit = (c.t != LP_F32_MAX);
         if (!hit) break;
         total += c.t;
-        if (!(sc.instances[c.inst].flags & 1u)) break;
+        if (OPAQUE || !(sc.instances[c.inst].flags & 1u)) break;
         Surface s = resolve_surface(sc, c.inst, c.tri, c.u, c.v);
         float opacity = surface_opacity(sc, s);
         if (opacity < 1.0f && rnd(rng) >= opacity) o = add(o, scale(d, c.t));
@@ -258,7 +261,7 @@ __device__ __forceinline__ void trace_alpha(const Geo &geo, const SceneDev &sc, 
     hit_tri = c.tri;
 }
 
-template <int TYPE, bool LDSGEO>
+template <int TYPE, bool LDSGEO, bool OPAQUE>
 __global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launch_bounds__(LP_BLOCK) k_extend(SceneDev sc, const FrameParams *__restrict__ fpp, PathBuffers pb, uint32_t iter,
                                                      unsigned long long *shard_stats, uint32_t stack_words)
 {
@@ -287,7 +290,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launc
     const uint32_t rng_in = rng;
     float4 hitrec;
     uint32_t hit_tri;
-    trace_alpha(geo, sc, lds_stack, mk3(orr.x, orr.y, orr.z), mk3(dm.x, dm.y, dm.z), rng, fp.pc.ray_epsilon, hitrec, hit_tri);
+    trace_alpha<typename GeoOf<LDSGEO>::type, OPAQUE>(geo, sc, lds_stack, mk3(orr.x, orr.y, orr.z), mk3(dm.x, dm.y, dm.z), rng, fp.pc.ray_epsilon, hitrec, hit_tri);
     pb.hit[slot] = hitrec;
     pb.hit_tri[slot] = hit_tri;
     if (rng != rng_in) pb.ori_rng[slot].w = __uint_as_float(rng);
@@ -558,7 +561,7 @@ struct PathRegs
 // path continues with (ori, dir) set for the next bounce, false on `break`.
 // TYPE 0: pathtrace_standard (:588-733)   1: pathtrace_mis (:737-933)
 //      2: pathtrace_naive (:942-1059)     3: pathtrace_direct (:1062-1245)
-template <int TYPE, typename Geo>
+template <int TYPE, typename Geo, bool SIMPLE = false>
 __device__ bool integrate_vertex(const Geo &geo, const SceneDev &sc, uint32_t *stack, const FrameParams &fp, PathRegs &p,
                                  float4 hitrec, uint32_t hit_tri, ShadowRays &sh)
 {
@@ -593,7 +596,7 @@ __device__ bool integrate_vertex(const Geo &geo, const SceneDev &sc, uint32_t *s
     {
         hit_pos = add(p.ori, scale(p.dir, hit_dst));
         const Surface s = resolve_surface(sc, hit_inst, hit_tri, hitrec.y, hitrec.z);
-        const MatPoint mp = material_point(sc, s);
+        const MatPoint mp = material_point<SIMPLE>(sc, s);
         const f3 normal = shading_normal(geo, sc, s);
 
         if (TYPE == LUPIN_PATHTRACE_STANDARD || TYPE == LUPIN_PATHTRACE_NAIVE || p.next_emission)
@@ -744,7 +747,7 @@ __device__ bool integrate_vertex(const Geo &geo, const SceneDev &sc, uint32_t *s
 
 // Everything of one integrator-loop iteration after the closest-hit query, for one path; writes the path state
 // back and returns whether the pixel still has work (the path continues, or its next camera sample was started).
-template <int TYPE, typename Geo>
+template <int TYPE, typename Geo, bool SIMPLE = false>
 __device__ __forceinline__ bool shade_path(const Geo &geo, const SceneDev &sc, uint32_t *stack, const FrameParams &fp, PathBuffers &pb,
                                            uint32_t slot, float4 orr, float4 dm, uint32_t rng, float4 hitrec, uint32_t hit_tri)
 {
@@ -760,7 +763,7 @@ __device__ __forceinline__ bool shade_path(const Geo &geo, const SceneDev &sc, u
     p.radiance = mk3(r4.x, r4.y, r4.z);
     p.rng = rng;
     p.bounce = (int)(meta & META_BOUNCE_MASK);
-    p.in_medium = (meta & META_VOLUME) != 0;
+    p.in_medium = SIMPLE ? false : (meta & META_VOLUME) != 0;   // matte surfaces never open a medium
     p.next_emission = (meta & META_NEXT_EMISSION) != 0;
     uint32_t sample = meta >> META_SAMPLE_SHIFT;
     const bool was_in_medium = p.in_medium;
@@ -775,7 +778,7 @@ __device__ __forceinline__ bool shade_path(const Geo &geo, const SceneDev &sc, u
 
     ShadowRays sh;
     sh.v0 = sh.v1 = false;
-    bool cont = integrate_vertex<TYPE>(geo, sc, stack, fp, p, hitrec, hit_tri, sh);
+    bool cont = integrate_vertex<TYPE, Geo, SIMPLE>(geo, sc, stack, fp, p, hitrec, hit_tri, sh);
     if (cont)
     {
         p.bounce++;
@@ -851,11 +854,15 @@ __device__ __forceinline__ bool shade_path(const Geo &geo, const SceneDev &sc, u
     return alive;
 }
 
-template <int TYPE, bool LDSGEO>
-__global__ void __attribute__((amdgpu_waves_per_eu(TYPE == 1 ? LP_MIS_SHADE_WAVES : LP_SHADE_WAVES, 8))) __launch_bounds__(LP_BLOCK) k_shade(SceneDev sc, const FrameParams *__restrict__ fpp, PathBuffers pb, uint32_t iter,
+// SIMPLE: scenes of untextured matte surfaces without environments (LupinScene::simple_matte, decided at upload) get a
+// k_shade in which those facts are compile-time constants: same arithmetic on the paths that exist, none of the code
+// for the ones that cannot.
+template <int TYPE, bool LDSGEO, bool SIMPLE>
+__global__ void __attribute__((amdgpu_waves_per_eu(TYPE == 1 ? LP_MIS_SHADE_WAVES : (SIMPLE ? LP_SIMPLE_SHADE_WAVES : LP_SHADE_WAVES), 8))) __launch_bounds__(LP_BLOCK) k_shade(SceneDev sc, const FrameParams *__restrict__ fpp, PathBuffers pb, uint32_t iter,
                                                     unsigned long long *shard_stats, uint32_t stack_words)
 {
     const FrameParams fp = *fpp;
+    if (SIMPLE) { sc.num_envs = 0; sc.sort_shade = 0; }   // facts of a simple_matte scene, constant from here on
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     const auto geo = make_geo<LDSGEO>(sc, lds_stack, stack_words);
     const uint32_t shard = blockIdx.x % LP_SHARDS;
@@ -893,7 +900,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(TYPE == 1 ? LP_MIS_SHADE_WAVE
     if (mine)
     {
         const float4 orr = pb.ori_rng[slot];
-        alive = shade_path<TYPE>(geo, sc, lds_stack, fp, pb, slot, orr, pb.dir_meta[slot], __float_as_uint(orr.w), pb.hit[slot], pb.hit_tri[slot]);
+        alive = shade_path<TYPE, typename GeoOf<LDSGEO>::type, SIMPLE>(geo, sc, lds_stack, fp, pb, slot, orr, pb.dir_meta[slot], __float_as_uint(orr.w), pb.hit[slot], pb.hit_tri[slot]);
     }
     if (i == 0 && iter == 0) shard_stats[shard * 2 + 1] += (unsigned long long)count * fp.spp;
     if (TYPE == LUPIN_PATHTRACE_MIS || TYPE == LUPIN_PATHTRACE_DIRECT) return;   // k_shadow appends
@@ -1411,6 +1418,7 @@ struct LupinContext
     uint32_t num_cus = 256;
     int blocks_per_cu_override = 0; // LUPIN_EXTEND_BLOCKS_PER_CU
     uint32_t refill_min = LP_REFILL_MIN;   // LUPIN_REFILL_MIN
+    bool specialize_simple = true;          // LUPIN_SIMPLE_SHADE=0: always the general k_shade
     bool use_graph = true;                  // LUPIN_GRAPH=0: launch every stage kernel individually
     bool persistent_shadow = true;          // LUPIN_SHADOW=simple: MIS / Direct shadow rays stay in k_shadow even on large scenes
     uint32_t node_steps = 4;               // LUPIN_NODE_STEPS: node visits per scheduling round of k_extend_persistent
@@ -1447,6 +1455,8 @@ struct LupinScene
     uint32_t stack_entries = 1;
     uint32_t persistent_blocks[4] = {0, 0, 0, 0};   // grid of k_extend_persistent per integrator (lazy)
     uint64_t id = 0;                                // unique per created scene (graph cache key)
+    bool all_opaque = false;                        // no instance can have opacity != 1: k_extend<.., OPAQUE> drops the alpha test
+    bool simple_matte = false;                      // only untextured matte materials, no vertex colours, no environments: k_shade<.., SIMPLE>
     bool has_sw_bvh = false;
     bool envs_empty = true, lights_empty = true, instances_empty = true;
 };
@@ -1569,9 +1579,17 @@ static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *sc
         hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, 0>), dim3(pblocks), dim3(LP_BLOCK), lds, st,
                            scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words, ctx->node_steps);
     else
-        hipLaunchKernelGGL((k_extend<TYPE, LDSGEO>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
+    {
+        if (scene->all_opaque && ctx->specialize_simple)
+            hipLaunchKernelGGL((k_extend<TYPE, LDSGEO, true>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
+        else
+            hipLaunchKernelGGL((k_extend<TYPE, LDSGEO, false>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
+    }
     if (ctx->timing) hipEventRecord(e1, st);
-    hipLaunchKernelGGL((k_shade<TYPE, LDSGEO>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
+    if (scene->simple_matte && ctx->specialize_simple)
+        hipLaunchKernelGGL((k_shade<TYPE, LDSGEO, true>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
+    else
+        hipLaunchKernelGGL((k_shade<TYPE, LDSGEO, false>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
     if constexpr (TYPE == LUPIN_PATHTRACE_MIS || TYPE == LUPIN_PATHTRACE_DIRECT)   // shadow rays + path finish (booked with "shade" in the timing)
     {
         if (persistent && ctx->persistent_shadow)
@@ -1688,6 +1706,8 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
         if (bpc) ctx->blocks_per_cu_override = std::max(0, atoi(bpc));
         ctx->num_cus = (uint32_t)prop.multiProcessorCount;
     }
+    const char *ssh = getenv("LUPIN_SIMPLE_SHADE");
+    if (ssh && strcmp(ssh, "0") == 0) ctx->specialize_simple = false;
     const char *gr = getenv("LUPIN_GRAPH");
     if (gr && strcmp(gr, "0") == 0) ctx->use_graph = false;
     const char *shd = getenv("LUPIN_SHADOW");
@@ -1976,6 +1996,7 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
     // ---- instances ----
     std::vector<InstanceDev> instances(s.num_instances);
     uint32_t mat_types_seen = 0;
+    bool any_alpha = false;
     for (uint32_t i = 0; i < s.num_instances; i++)
     {
         const LupinInstance &in = s.instances[i];
@@ -1991,6 +2012,7 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
         bool maybe_alpha = !(mat.color[3] == 1.0f) ||
                            (mat.color_tex_idx != LUPIN_SENTINEL_IDX && meshes[in.mesh_idx].texcoords_base != LUPIN_SENTINEL_IDX) ||
                            meshes[in.mesh_idx].colors_base != LUPIN_SENTINEL_IDX;
+        any_alpha = any_alpha || maybe_alpha;
         d.flags = (maybe_alpha ? 1u : 0u) | ((mat.mat_type & 0xFu) << 8);   // bits 8..11: material type = k_shade's sort key
         mat_types_seen |= 1u << (mat.mat_type & 0xFu);
         instances[i] = d;
@@ -2112,6 +2134,19 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
     dv.num_lights = s.num_lights;
     dv.num_envs = s.num_environments;
     dv.num_instances = s.num_instances;
+    {
+        // simple_matte: every instance's material is matte with no texture reference, no mesh carries vertex colours, and
+        // there is no environment -- then material type, texture use and environment terms are constants of the scene
+        bool simple = s.num_instances > 0 && s.num_environments == 0 && s.num_color_buffers == 0;
+        for (uint32_t i = 0; i < s.num_instances && simple; i++)
+        {
+            const LupinMaterial &mat = s.materials[s.instances[i].mat_idx];
+            simple = mat.mat_type == LUPIN_MAT_MATTE && mat.color_tex_idx == LUPIN_SENTINEL_IDX && mat.emission_tex_idx == LUPIN_SENTINEL_IDX &&
+                     mat.roughness_tex_idx == LUPIN_SENTINEL_IDX && mat.scattering_tex_idx == LUPIN_SENTINEL_IDX && mat.normal_tex_idx == LUPIN_SENTINEL_IDX;
+        }
+        sc->simple_matte = simple;
+        sc->all_opaque = !any_alpha;
+    }
     dv.sort_shade = __builtin_popcount(mat_types_seen) >= 4;   // pays off from about four BSDF families (measured: 3 lose 10 %, 8 win 17 % of k_shade)
     { const char *ss = getenv("LUPIN_SORT_SHADE"); if (ss) dv.sort_shade = strcmp(ss, "0") != 0; }
     dv.geo_blob_words = (uint32_t)geo_blob.size();
