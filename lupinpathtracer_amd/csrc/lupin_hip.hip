@@ -2406,10 +2406,10 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
         key.refill_min = ctx->refill_min; key.node_steps = ctx->node_steps; key.persistent = ctx->persistent_extend;
         key.persistent_shadow = ctx->persistent_shadow ? 1 : 0; key.lds_geometry = lds_geo ? 1 : 0;
         const bool have = ln->graph_exec && key == ln->graph_key;
-        if (!have && !(key == ln->seen_key))
+        if (!have && ln->graph_exec && !(key == ln->seen_key))
         {
-            // first call of this shape on the lane (or shapes alternate, e.g. edge tiles): capturing costs about a
-            // millisecond, so launch directly and capture only if the shape repeats
+            // the lane holds a graph of another shape and this one is new (shapes alternate, e.g. edge tiles): capturing
+            // costs about a millisecond, so launch directly and re-capture only if the shape repeats
             ln->seen_key = key;
             HIP_TRY(enqueue_wavefront(ctx, ln, scene, pathtrace_type, lds_geo, n, blocks, pblocks, lds, stack_words, iterations));
         }

@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--spp", type=int, default=8)
     ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--type", type=int, default=0)
     ap.add_argument("--blas", default="sah", choices=["sah", "lbvh"], help="BLAS builder: reference CPU SAH or the device LBVH")
     args = ap.parse_args()
