@@ -1419,7 +1419,7 @@ struct LupinContext
     int blocks_per_cu_override = 0; // LUPIN_EXTEND_BLOCKS_PER_CU
     uint32_t refill_min = LP_REFILL_MIN;   // LUPIN_REFILL_MIN
     bool specialize_simple = true;          // LUPIN_SIMPLE_SHADE=0: always the general k_shade
-    bool use_graph = true;                  // LUPIN_GRAPH=0: launch every stage kernel individually
+    bool use_graph = false;                 // LUPIN_GRAPH=1: replay the lane-private wavefront as a HIP graph (opt-in)
     bool persistent_shadow = true;          // LUPIN_SHADOW=simple: MIS / Direct shadow rays stay in k_shadow even on large scenes
     uint32_t node_steps = 4;               // LUPIN_NODE_STEPS: node visits per scheduling round of k_extend_persistent
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_extend, ev_shade, ev_total;
@@ -1709,7 +1709,7 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
     const char *ssh = getenv("LUPIN_SIMPLE_SHADE");
     if (ssh && strcmp(ssh, "0") == 0) ctx->specialize_simple = false;
     const char *gr = getenv("LUPIN_GRAPH");
-    if (gr && strcmp(gr, "0") == 0) ctx->use_graph = false;
+    if (gr) ctx->use_graph = strcmp(gr, "0") != 0;
     const char *shd = getenv("LUPIN_SHADOW");
     if (shd && strcmp(shd, "simple") == 0) ctx->persistent_shadow = false;
     const char *ns = getenv("LUPIN_NODE_STEPS");
