@@ -1,0 +1,153 @@
+"""Randomised parity: small synthetic scenes that mix what the reference's test scenes do not (every material type incl.
+subsurface / gltfpbr, emission / roughness / scattering / normal textures, vertex colours, partial opacity, several
+environments with and without textures, scaled and sheared instances, orthographic and thin-lens cameras), rendered by
+the HIP path and by the oracle on the same RNG streams.  SURVEY 8d: "oracle-only coverage via synthetic materials"."""
+import numpy as np
+import pytest
+
+from lupinpathtracer_amd import api, loader
+from lupinpathtracer_amd._abi import ENVIRONMENT_DTYPE, INSTANCE_DTYPE, MATERIAL_DTYPE, MESH_INFO_DTYPE
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def box_mesh():
+    v = np.array([(x, y, z) for x in (-0.5, 0.5) for y in (-0.5, 0.5) for z in (-0.5, 0.5)], np.float32)
+    f = [(0, 1, 3), (0, 3, 2), (4, 6, 7), (4, 7, 5), (0, 4, 5), (0, 5, 1), (2, 3, 7), (2, 7, 6), (0, 2, 6), (0, 6, 4), (1, 5, 7), (1, 7, 3)]
+    return v, np.array(f, np.uint32).reshape(-1)
+
+
+def grid_mesh(n, rng):
+    """(n+1)^2 vertices, bumpy height field with uvs, normals, colours."""
+    u, w = np.meshgrid(np.linspace(0, 1, n + 1), np.linspace(0, 1, n + 1), indexing="ij")
+    h = 0.08 * np.sin(7 * u + rng.uniform(0, 6)) * np.cos(5 * w + rng.uniform(0, 6))
+    v = np.stack([u - 0.5, h, w - 0.5], -1).reshape(-1, 3).astype(np.float32)
+    idx = []
+    for i in range(n):
+        for j in range(n):
+            a, b, c, d = i * (n + 1) + j, (i + 1) * (n + 1) + j, (i + 1) * (n + 1) + j + 1, i * (n + 1) + j + 1
+            idx += [a, c, b, a, d, c]
+    uv = np.stack([u * 3, w * 2], -1).reshape(-1, 2).astype(np.float32)
+    nrm = np.zeros_like(v); nrm[:, 1] = 1.0
+    nrm[:, 0] = -0.3 * np.cos(7 * v[:, 0]); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    col = rng.uniform(0.4, 1.0, (len(v), 4)).astype(np.float32)
+    return v, np.array(idx, np.uint32), uv, nrm.astype(np.float32), col
+
+
+def pad4(a, w=0.0):
+    out = np.full((len(a), 4), w, np.float32)
+    out[:, :a.shape[1]] = a
+    return out
+
+
+def random_scene(seed):
+    rng = np.random.default_rng(seed)
+    s = api.SceneCPU()
+    infos = []
+    bv, bi = box_mesh()
+    s.verts_pos_array.append(pad4(bv)); s.indices_array.append(bi); infos.append(api.default_mesh_info())            # 0: box
+    gv, gi, guv, gn, gc = grid_mesh(6, rng)
+    s.verts_pos_array.append(pad4(gv)); s.indices_array.append(gi)
+    s.verts_texcoord_array.append(guv); s.verts_normal_array.append(pad4(gn)); s.verts_color_array.append(gc)
+    info = api.default_mesh_info(); info["texcoords_buf_idx"] = 0; info["normals_buf_idx"] = 0; info["colors_buf_idx"] = 0
+    infos.append(info)                                                                                              # 1: grid with every attribute
+    gv2, gi2, guv2, _, _ = grid_mesh(3, rng)
+    s.verts_pos_array.append(pad4(gv2)); s.indices_array.append(gi2); s.verts_texcoord_array.append(guv2)
+    info = api.default_mesh_info(); info["texcoords_buf_idx"] = 1
+    infos.append(info)                                                                                              # 2: grid with uvs only
+    s.mesh_infos = np.array(infos, MESH_INFO_DTYPE)
+
+    # textures: 0 RGBA8 colour with alpha holes, 1 RGBA8 roughness / metallic, 2 RGBA16F emission, 3 RGBA8 normal map, 4 RGBA16F sky
+    t0 = rng.integers(0, 256, (16, 16, 4), dtype=np.uint8); t0[..., 3] = np.where(rng.random((16, 16)) < 0.3, 90, 255)
+    t1 = rng.integers(0, 256, (8, 8, 4), dtype=np.uint8)
+    t2 = np.ones((8, 4, 4), np.float16); t2[..., :3] = rng.uniform(0, 2, (8, 4, 3)).astype(np.float16)
+    t3 = np.zeros((16, 16, 4), np.uint8); t3[..., :2] = rng.integers(96, 160, (16, 16, 2)); t3[..., 2] = 255; t3[..., 3] = 255
+    sky32 = np.ones((8, 16, 4), np.float32); sky32[..., :3] = rng.uniform(0.05, 1.5, (8, 16, 3)); sky32[2, 5, :3] = 40.0
+    textures = [api.TextureCPU(t0), api.TextureCPU(t1), api.TextureCPU(t2), api.TextureCPU(t3), api.TextureCPU(sky32.astype(np.float16))]
+
+    mats = []
+    for t in range(8):
+        for variant in range(2):
+            m = api.default_material()
+            m["mat_type"] = t
+            m["color"] = (*rng.uniform(0.2, 0.95, 3), 1.0 if variant == 0 else rng.uniform(0.3, 1.0))
+            m["roughness"] = [0.0, 0.25, 0.2, 0.0, 0.0, 0.15, 0.0, 0.35][t] if variant == 0 else rng.uniform(0.0, 0.6)
+            m["metallic"] = rng.uniform(0, 1)
+            m["ior"] = rng.uniform(1.1, 2.0)
+            m["scattering"][:3] = rng.uniform(0.05, 0.9, 3)
+            m["sc_anisotropy"] = rng.uniform(-0.6, 0.6)
+            m["tr_depth"] = rng.uniform(0.02, 0.5)
+            if variant == 1:
+                m["color_tex_idx"] = 0 if t % 2 == 0 else api.SENTINEL_IDX
+                m["roughness_tex_idx"] = 1 if t in (1, 2, 7) else api.SENTINEL_IDX
+                m["scattering_tex_idx"] = 1 if t in (5, 6) else api.SENTINEL_IDX
+                m["normal_tex_idx"] = 3 if t in (0, 1, 2, 7) else api.SENTINEL_IDX
+            mats.append(m)
+    em = api.default_material(); em["emission"][:3] = (14, 11, 6); mats.append(em)                       # plain emitter
+    em2 = api.default_material(); em2["emission"][:3] = (5, 6, 9); em2["emission_tex_idx"] = 2; mats.append(em2)   # textured emitter
+    s.materials = np.array(mats, MATERIAL_DTYPE)
+
+    def frame(scale3, yaw, pitch, pos, shear=0.0):
+        cy, sy, cp, sp = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch)
+        r = np.array([[cy, 0, -sy], [sy * sp, cp, cy * sp], [sy * cp, -sp, cy * cp]], np.float64)   # rows = columns of the frame
+        f = np.zeros((4, 3), np.float32)
+        f[0] = r[0] * scale3[0]; f[1] = r[1] * scale3[1] + shear * r[0]; f[2] = r[2] * scale3[2]; f[3] = pos
+        return f
+
+    insts = [api.instance_from_transform(frame((6, 6, 6), 0.0, 0.0, (0, -0.2, 2.5)), 2, 0)]              # floor (matte, uvs)
+    for i in range(14):
+        mesh = int(rng.integers(0, 3))
+        mat = int(rng.integers(0, 16))
+        sc = rng.uniform(0.3, 0.9, 3) * (1.0 if mesh == 0 else 1.6)
+        pos = (rng.uniform(-1.6, 1.6), rng.uniform(0.0, 1.2), rng.uniform(1.2, 3.8))
+        insts.append(api.instance_from_transform(frame(sc, rng.uniform(0, 6.28), rng.uniform(-0.5, 0.5), pos, shear=rng.uniform(-0.2, 0.2)), mesh, mat))
+    insts.append(api.instance_from_transform(frame((0.5, 0.5, 0.5), 0.3, 0.0, (0.3, 2.2, 2.4)), 0, 16))   # box light
+    insts.append(api.instance_from_transform(frame((0.8, 0.8, 0.8), 1.0, 0.4, (-1.0, 1.8, 3.0)), 2, 17))  # textured emitter with uvs
+    s.instances = np.array(insts, INSTANCE_DTYPE)
+
+    envs = []
+    e0 = api.default_environment(); e0["emission"] = (0.5, 0.55, 0.7); e0["emission_tex_idx"] = 4
+    rot = frame((1, 1, 1), 0.7, 0.2, (0, 0, 0)); e0["transform"][:3, :3] = rot[:3]
+    envs.append(e0)
+    if seed % 2 == 0:
+        e1 = api.default_environment(); e1["emission"] = (0.05, 0.04, 0.03); envs.append(e1)   # constant environment, no texture
+    s.environments = np.array(envs, ENVIRONMENT_DTYPE)
+    envs_info = [api.EnvMapInfo(sky32, 16, 8)] + ([api.EnvMapInfo(np.ones((1, 1, 4), np.float32), 1, 1)] if seed % 2 == 0 else [])
+    api.validate_scene(s, len(textures), len(textures))
+
+    cam = loader.SceneCamera(transform=np.array([[1, 0, 0], [0, 0.96, 0.28], [0, -0.28, 0.96], [0, 1.3, -1.2]], np.float32),
+                             params=api.CameraParams(lens=0.03, film=0.036, aspect=1.5, focus=3.5, aperture=0.0))
+    cam_dof = loader.SceneCamera(transform=cam.transform, params=api.CameraParams(lens=0.05, film=0.036, aspect=1.5, focus=3.0, aperture=0.08))
+    cam_ortho = loader.SceneCamera(transform=cam.transform, params=api.CameraParams(is_orthographic=True, lens=0.05, film=3.0, aspect=1.5, focus=3.0, aperture=0.0))
+    return s, textures, envs_info, [cam, cam_dof, cam_ortho]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_scene_parity(gpu_ctx, seed):
+    scene_cpu, textures, envs_info, cams = random_scene(seed)
+    scene = api.build_accel_structures_and_upload(gpu_ctx, scene_cpu, textures, envs_info)
+    W, H = 120, 80
+    for ptype in range(4):
+        cam = cams[(seed + ptype) % 3]
+        got = util.gpu_accumulate(gpu_ctx, scene, cam, W, H, frames=2, spp=3, max_bounces=7, ptype=ptype)
+        ref = util.oracle_accumulate(scene, cam, W, H, frames=2, spp=3, max_bounces=7, ptype=ptype)
+        g, r = got.astype(np.float32), ref.astype(np.float32)
+        assert np.isfinite(g).all()
+        rmse = float(np.sqrt(((g[..., :3] - r[..., :3]) ** 2).mean()))
+        nbad = util.f16_words_differ(got, ref)
+        assert rmse < 1e-3 and nbad <= 1e-3 * got.size, f"seed {seed} type {ptype}: rmse {rmse}, {nbad} words differ"
+        assert g[..., :3].max() > 0.05   # the scene is lit
+    # G-buffers and heat maps on the same scene
+    from oracle import oracle
+    res = api.build_pathtrace_resources(gpu_ctx, api.BakedPathtraceParams(max_bounces=7, samples_per_pixel=2))
+    desc = api.PathtraceDesc(camera_params=cams[0].params, camera_transform=cams[0].transform)
+    tex = api.Texture(gpu_ctx, W, H)
+    for ft in (api.FalsecolorType.Albedo, api.FalsecolorType.Normals, api.FalsecolorType.Emission, api.FalsecolorType.Opacity, api.FalsecolorType.IsDelta):
+        api.pathtrace_scene_falsecolor(gpu_ctx, res, scene, tex, ft, desc)
+        ref, _ = oracle.pathtrace(scene, W, H, cams[0].params, cams[0].transform, 7, 2, falsecolor_type=ft)
+        assert util.f16_words_differ(tex.download(), ref) <= 1e-3 * ref.size, ft
+    dd = api.DebugVizDesc(api.DebugVizType.BVHTriChecks, 0.0, 300.0, False)
+    api.pathtrace_scene_debug(gpu_ctx, res, scene, tex, dd, desc)
+    ref, _ = oracle.pathtrace(scene, W, H, cams[0].params, cams[0].transform, 7, 2, debug_desc=dd)
+    assert util.f16_words_differ(tex.download(), ref) <= 1e-3 * ref.size
