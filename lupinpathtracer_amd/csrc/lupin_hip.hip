@@ -296,12 +296,14 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launc
     if (rng != rng_in) pb.ori_rng[slot].w = __uint_as_float(rng);
 }
 
-// Persistent form of k_extend.  Rays of one wave need very different numbers of traversal steps (Cornell box:
-// 4 .. 25 node visits), so a one-ray-per-lane kernel keeps only ~36 % of the lanes busy (PMC: SQ_THREAD_CYCLES_VALU /
-// (SQ_ACTIVE_INST_VALU * 64)).  Here each wave owns its lanes for the whole launch and refills idle lanes whenever at
-// least LP_REFILL_MIN of them have finished.  Work is partitioned statically, so refilling needs no atomics: the
-// grid holds `wps` waves per shard, and wave j of shard s owns the 64-entry chunks j, j + wps, j + 2 wps, ... of that
-// shard's queue.  Every ray is still traced exactly as in k_extend, only by a different lane.
+// Persistent, phase-scheduled form of k_extend -- the default for scenes traversed from global memory.  Rays of one
+// wave need very different numbers of traversal steps and sit in different phases of the traversal, so the
+// one-ray-per-lane kernel keeps 11 % of the VALU lanes busy on the bistro-class scene (39 % on the Cornell box; PMC:
+// SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU * 64)).  Here each wave owns its lanes for the whole launch, refills empty
+// lanes whenever at least `refill_min` of them are free, and executes per round the one phase most lanes wait for.
+// Work is partitioned statically, so refilling needs no atomics: the grid holds `wps` waves per shard, and wave j of
+// shard s owns the 64-entry chunks j, j + wps, j + 2 wps, ... of that shard's queue.  Every ray is still traced by
+// exactly the same sequence of operations as in k_extend, only by a different lane.
 #ifndef LP_REFILL_MIN
 #define LP_REFILL_MIN 16
 #endif
