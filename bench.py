@@ -6,8 +6,8 @@
 A step = one `pathtrace_scene` accumulation frame (samples_per_pixel = 8, 8 bounces, Standard integrator) of
 the Cornell box -- BASELINE.json configs[1] (cornellbox 1024 x 1024, 8 bounces; its 1024 spp are 128 such
 frames, Msamples/s does not depend on how many are timed).  With N > 1 (one rank per GPU, torch.distributed
-over RCCL) the image grows with N (weak scaling: 1024^2 pixels per GPU) and its tiles are dealt round-robin to
-the ranks; no collective runs while accumulating, the timed region ends with the one all-gather of tile
+over RCCL) the image grows with N (weak scaling: the same view at N x 1024^2 pixels) and its tiles are dealt round-robin
+to the ranks; no collective runs while accumulating, the timed region ends with the one all-gather of tile
 payloads that a readback needs.
 
 The JSON line also carries
@@ -18,6 +18,7 @@ The JSON line also carries
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -33,15 +34,14 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-def image_size_for(n_gpus, base):
-    """base^2 pixels per GPU: 1 -> 1x1, 2 -> 2x1, 4 -> 2x2, 8 -> 4x2 blocks of base x base."""
-    bx = 1
-    while bx * bx < n_gpus:
-        bx *= 2
-    by = max(1, n_gpus // bx)
-    while bx * by < n_gpus:
-        by += 1
-    return base * bx, base * by
+def image_size_for(n_gpus, base, tile_px):
+    """Weak scaling: base^2 pixels per GPU of the SAME view -- a square image of about n * base^2 pixels whose side is a
+    whole number of tiles (1 -> 1024, 2 -> 1440, 4 -> 2048, 8 -> 2912 with 32-pixel tiles: within 1.2 % of 1024^2 per
+    GPU), so every rank owns whole tiles only (equal pixel counts whatever the round-robin pattern) carrying the same
+    mix of paths as the single-GPU frame.  A wider image would instead add empty space around the box: cheaper paths,
+    a different workload."""
+    side = max(1, int(round(base * math.sqrt(n_gpus) / tile_px))) * tile_px
+    return side, side
 
 
 def main():
@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--size", type=int, default=1024, help="pixels per side per GPU")
     ap.add_argument("--spp", type=int, default=8, help="samples per pixel per step (baked)")
     ap.add_argument("--bounces", type=int, default=8)
-    ap.add_argument("--tile-size", type=int, default=32, help="tile edge in 4-px workgroups for multi-GPU sharding")
+    ap.add_argument("--tile-size", type=int, default=8, help="tile edge in 4-px workgroups for multi-GPU sharding")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel hipEvent pass (roofline = null)")
     args = ap.parse_args()
@@ -81,7 +81,7 @@ def main():
 
     scene, cams = loader.build_scene_cornell_box(ctx)
     cam = cams[0]
-    W, H = image_size_for(world, args.size)
+    W, H = image_size_for(world, args.size, args.tile_size * 4)
     cam_params = api.CameraParams(**{**cam.params.__dict__, "aspect": cam.params.aspect * W / H})
     res = api.build_pathtrace_resources(ctx, api.BakedPathtraceParams(max_bounces=args.bounces, samples_per_pixel=args.spp))
     out = api.DoubleBufferedTexture(ctx, W, H)
@@ -211,7 +211,7 @@ def main():
             "metric": "Msamples/sec (paths x bounces)", "value": value, "unit": "Msamples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"cornellbox {W}x{H} ({args.size}^2 px per GPU), {args.bounces} bounces, "
+            "config": {"workload": f"cornellbox {W}x{H} ({W * H / world / 1e6:.3f} Mpx per GPU), {args.bounces} bounces, "
                                    f"{args.spp} spp per step, Standard integrator, software BVH",
                        "scene": "built-in Cornell box (8 instances, 36 triangles, 1 area light)",
                        "samples_per_pixel_per_step": args.spp, "spp_total_timed": args.spp * args.steps,
