@@ -90,8 +90,10 @@ class HipTileOps:
 
     def unpack(self, texture, payload, tile_size, rank, world):
         from . import api
-        api.unpack_tiles(self.ctx, texture, tile_size, rank, world, payload.data_ptr())
-        self.ctx.sync()
+        api.unpack_tiles(self.ctx, texture, tile_size, rank, world, payload.data_ptr())   # enqueued; finish() waits
+
+    def finish(self):
+        self.ctx.sync()   # the payload tensors may be released after this
 
 
 def gather_framebuffer(dist, ops, framebuffer, width, height, tile_size, rank, world):
@@ -107,4 +109,6 @@ def gather_framebuffer(dist, ops, framebuffer, width, height, tile_size, rank, w
     for r in range(world):
         if r != rank:
             ops.unpack(framebuffer, gathered[r * mine.numel():(r + 1) * mine.numel()], tile_size, r, world)
+    if hasattr(ops, "finish"):
+        ops.finish()
     return capacity * 8
