@@ -37,3 +37,10 @@ def test_distributed_bench_path_on_one_gpu(built):
     env = {"LUPIN_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"}
     d = run_bench(env, "--steps", "6", "--warmup", "4", "--no-cpu-baseline")
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["path_bounces"] > 0
+
+
+def test_gather_framebuffer_with_device_payloads(built):
+    """distributed.gather_framebuffer + HipTileOps (torch CUDA payloads, pack / unpack kernels) for world 3 on one GPU
+    (tests/_gather_worker.py; its own process because torch brings its own HIP runtime, which has to load first)."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_gather_worker.py")], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "GATHER OK" in p.stdout, p.stdout[-1500:] + p.stderr[-1500:]
