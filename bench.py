@@ -36,12 +36,14 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 def image_size_for(n_gpus, base, tile_px):
     """Weak scaling: base^2 pixels per GPU of the SAME view -- a square image of about n * base^2 pixels whose side is a
-    whole number of tiles (1 -> 1024, 2 -> 1440, 4 -> 2048, 8 -> 2912 with 32-pixel tiles: within 1.2 % of 1024^2 per
+    whole number of tiles (1 -> 1024, 2 -> 1440, 4 -> 2080, 8 -> 2912 with 32-pixel tiles: within 3.2 % of 1024^2 per
     GPU), so every rank owns whole tiles only (equal pixel counts whatever the round-robin pattern) carrying the same
     mix of paths as the single-GPU frame.  A wider image would instead add empty space around the box: cheaper paths,
     a different workload."""
-    side = max(1, int(round(base * math.sqrt(n_gpus) / tile_px))) * tile_px
-    return side, side
+    tiles = max(1, int(round(base * math.sqrt(n_gpus) / tile_px)))
+    if n_gpus > 1 and tiles % n_gpus == 0:
+        tiles += 1   # round-robin over a row length that is a multiple of N would give every rank fixed columns (stripes)
+    return tiles * tile_px, tiles * tile_px
 
 
 def main():

@@ -10,7 +10,9 @@ res = api.build_pathtrace_resources(ctx, api.BakedPathtraceParams(max_bounces=8,
 TILE = 8
 base = None
 for world in (1, 2, 4, 8):
-    side = max(1, int(round(1024 * math.sqrt(world) / (TILE * 4)))) * TILE * 4
+    tiles = max(1, int(round(1024 * math.sqrt(world) / (TILE * 4))))
+    if world > 1 and tiles % world == 0: tiles += 1
+    side = tiles * TILE * 4
     out = api.DoubleBufferedTexture(ctx, side, side)
     rates, units = [], []
     for rank in (range(world) if world <= 4 else (0, 3, 7)):
