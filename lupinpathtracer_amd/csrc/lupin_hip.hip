@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <atomic>
 
 #include "lupin_stages.hpp"
 
@@ -802,8 +803,8 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
     { const char *ss = getenv("LUPIN_SORT_SHADE"); if (ss) dv.sort_shade = strcmp(ss, "0") != 0; }
     dv.geo_blob_words = (uint32_t)geo_blob.size();
     dv.geo_off_blas = off_blas; dv.geo_off_tris = off_tris; dv.geo_off_inst = off_inst;
-    static uint64_t next_scene_id = 1;
-    sc->id = next_scene_id++;
+    static std::atomic<uint64_t> next_scene_id{1};   // contexts may live on different host threads
+    sc->id = next_scene_id.fetch_add(1);
     hipError_t e = hipStreamSynchronize(ctx->stream);   // host vectors go out of scope
     if (e != hipSuccess) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_HIP, hipGetErrorString(e)); }
     *out_scene = sc;
