@@ -201,6 +201,10 @@ static uint32_t persistent_grid_t(LupinContext *ctx, const LupinScene *scene, si
     {
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extend_persistent<TYPE, LDSGEO, 0>, LP_BLOCK, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        // With frames in flight the persistent tracer of one frame shares the chip with the shading of another: when five
+        // or more of its blocks fit per CU, three leave that room and the pair finishes sooner (materials1 / environments1
+        // +5 %); deeper scenes fit four at most and are latency-bound, they keep them all (bistro-class -9 % with two).
+        if (ctx->num_lanes > 1 && per_cu > 4) per_cu = 3;
         if (ctx->blocks_per_cu_override > 0) per_cu = ctx->blocks_per_cu_override;
         cached = std::max(64u, ctx->num_cus * (uint32_t)per_cu / 64u * 64u);
     }
