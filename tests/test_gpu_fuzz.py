@@ -151,3 +151,60 @@ def test_random_scene_parity(gpu_ctx, seed):
     api.pathtrace_scene_debug(gpu_ctx, res, scene, tex, dd, desc)
     ref, _ = oracle.pathtrace(scene, W, H, cams[0].params, cams[0].transform, 7, 2, debug_desc=dd)
     assert util.f16_words_differ(tex.download(), ref) <= 1e-3 * ref.size
+
+
+def _random_api_mix(lanes, seed, n_ops):
+    import os
+    old = os.environ.get("LUPIN_LANES")
+    os.environ["LUPIN_LANES"] = str(lanes)
+    try:
+        ctx = api.Context(0)
+    finally:
+        if old is None:
+            os.environ.pop("LUPIN_LANES", None)
+        else:
+            os.environ["LUPIN_LANES"] = old
+    try:
+        rng = np.random.default_rng(seed)
+        scene, cams = loader.build_scene_cornell_box(ctx)
+        cam = cams[0]
+        res = api.build_pathtrace_resources(ctx, api.BakedPathtraceParams(max_bounces=5, samples_per_pixel=2))
+        W, H = 160, 96
+        out = api.DoubleBufferedTexture(ctx, W, H)
+        extra = api.Texture(ctx, W, H)
+        k, digest = 0, []
+        for _ in range(n_ops):
+            op = int(rng.integers(0, 10))
+            desc = api.PathtraceDesc(accum_params=api.AccumulationParams(out.back(), k), camera_params=cam.params, camera_transform=cam.transform)
+            if op <= 4:
+                api.pathtrace_scene(ctx, res, scene, out.front(), int(rng.integers(0, 4)), desc)
+                out.flip()
+                k += 1
+            elif op == 5:
+                t = int(rng.integers(0, api.get_num_tiles(6, W, H)))
+                api.pathtrace_scene(ctx, res, scene, out.front(), 0,
+                                    api.PathtraceDesc(accum_params=api.AccumulationParams(out.back(), k), tile_params=api.TileParams(6, t),
+                                                      camera_params=cam.params, camera_transform=cam.transform))
+            elif op == 6:
+                out.copy_front_to_back()
+            elif op == 7:
+                digest.append(int(out.front().download().view(np.uint16).astype(np.uint64).sum()))
+            elif op == 8:
+                api.pathtrace_scene_falsecolor(ctx, res, scene, extra, int(rng.integers(0, 12)),
+                                               api.PathtraceDesc(camera_params=cam.params, camera_transform=cam.transform))
+                digest.append(int(extra.download().view(np.uint16).astype(np.uint64).sum()))
+            else:
+                out.back().upload(out.back().download())
+        return digest, out.front().download().copy(), out.back().download().copy()
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_frames_in_flight_equal_a_serial_context(seed):
+    """600 random API calls (all integrators, tiles, copies, uploads, downloads, G-buffers) on a context with three frames
+    in flight and on a one-lane context: every checkpoint and both final textures are identical."""
+    a = _random_api_mix(3, seed, 600)
+    b = _random_api_mix(1, seed, 600)
+    assert a[0] == b[0] and len(a[0]) > 50
+    assert util.f16_words_differ(a[1], b[1]) == 0 and util.f16_words_differ(a[2], b[2]) == 0
