@@ -67,11 +67,22 @@ def main():
     for _ in range(min(2, args.steps)):
         step()
     kst = ctx.stats()
+    # fraction of the HBM roofline (8 TB/s) from the algorithmic bytes per path-bounce of the oracle's work accounting
+    # (tests/golden/work_counters.json: per-unit figures do not depend on the resolution) and the serial kernel times
+    roofline = None
+    with open(os.path.join(ROOT, "tests", "golden", "work_counters.json")) as f:
+        wc = json.load(f)
+    for rec in wc.values():
+        if rec["scene"] == args.scene and rec["max_bounces"] == args.bounces and rec["pathtrace_type"] == args.type and kst["path_bounces"] > 0:
+            roofline = {}
+            for kname, ms, per_unit in (("k_extend", kst["extend_ms"], rec["extend_bytes_per_unit"]), ("k_shade", kst["shade_ms"], rec["shade_bytes_per_unit"])):
+                achieved = per_unit * kst["path_bounces"] / (ms * 1e-3) / 1e9
+                roofline[kname] = {"bound": "hbm", "bytes_per_unit": per_unit, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0}
     print(json.dumps({"scene": args.scene, "camera": args.cam, "width": args.width, "height": args.height, "bounces": args.bounces,
                       "spp_per_step": args.spp, "steps": args.steps, "type": args.type, "Msamples_per_s": st["path_bounces"] / dt / 1e6,
                       "Mpaths_per_s": st["paths"] / dt / 1e6, "ms_per_step": dt / args.steps * 1e3,
                       "bounces_per_path": st["path_bounces"] / st["paths"], "scene_stats": scene.stats, "blas_builder": args.blas, "load_and_build_s": load_s,
-                      "kernel_ms_2steps": {"extend": kst["extend_ms"], "shade": kst["shade_ms"], "total": kst["total_ms"]}}))
+                      "kernel_ms_2steps": {"extend": kst["extend_ms"], "shade": kst["shade_ms"], "total": kst["total_ms"]}, "roofline": roofline}))
 
 
 if __name__ == "__main__":
