@@ -14,6 +14,7 @@
 #include <algorithm>
 
 #include "../../include/lupin_hip.h"
+#include "../../include/lupin_tiles.h"
 
 namespace {
 
@@ -487,8 +488,10 @@ uint64_t lupin_hip_packed_tile_pixels(uint32_t width, uint32_t height, uint32_t 
     uint32_t ntx = ((width > 1 ? width : 1) - 1) / tpx + 1;
     uint32_t nty = ((height > 1 ? height : 1) - 1) / tpx + 1;
     uint64_t total = 0;
-    for (uint32_t t = rank; t < ntx * nty; t += world)
+    const uint32_t owned = lupin_owned_tile_count(ntx * nty, rank, world);
+    for (uint32_t j = 0; j < owned; j++)
     {
+        const uint32_t t = lupin_owned_tile(j, rank, world, ntx);
         uint32_t ox = (t % ntx) * tpx, oy = (t / ntx) * tpx;
         uint32_t w = std::min(tpx, width - ox), h = std::min(tpx, height - oy);
         total += (uint64_t)w * h;

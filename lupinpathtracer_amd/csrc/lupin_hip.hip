@@ -973,7 +973,7 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
         const uint32_t tpx = set_tile_size * LUPIN_WORKGROUP_SIZE;
         const uint32_t ntx = (std::max(1u, W) - 1) / tpx + 1, nty = (std::max(1u, H) - 1) / tpx + 1;
         const uint32_t total = ntx * nty;
-        const uint32_t owned = (total > rank) ? (total - rank + world - 1) / world : 0;
+        const uint32_t owned = lupin_owned_tile_count(total, rank, world);
         fp.tile_px = tpx; fp.tiles_x = ntx; fp.rank = rank; fp.world = world;
         n64 = (uint64_t)owned * tpx * tpx;
     }

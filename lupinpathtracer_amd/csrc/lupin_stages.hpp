@@ -23,6 +23,7 @@
 #include <hip/hip_fp16.h>
 
 #include "lupin_device.hpp"
+#include "../../include/lupin_tiles.h"
 
 using namespace lpd;
 
@@ -141,7 +142,7 @@ __device__ __forceinline__ void slot_to_pixel(const FrameParams &fp, uint32_t sl
     if (fp.tile_px)
     {
         const uint32_t per_tile = fp.tile_px * fp.tile_px;
-        const uint32_t t = fp.rank + (slot / per_tile) * fp.world;
+        const uint32_t t = lupin_owned_tile(slot / per_tile, fp.rank, fp.world, fp.tiles_x);
         const uint32_t r = slot % per_tile;
         gx = (t % fp.tiles_x) * fp.tile_px + r % fp.tile_px;
         gy = (t / fp.tiles_x) * fp.tile_px + r / fp.tile_px;
@@ -1343,15 +1344,13 @@ __global__ void __launch_bounds__(LP_BLOCK) k_pack_tiles(const uint2 *tex, uint2
     if (x >= width || y >= height) return;
     uint32_t tx = x / tile_px, ty = y / tile_px;
     uint32_t t = ty * ntx + tx;
-    if (t % world != rank) return;
-    // pixels in owned tiles before tile t
+    if (lupin_tile_owner(t, ntx, world) != rank) return;
+    // pixels in this rank's tiles before tile t (tiles are few -- a few thousand at most -- so a loop is fine)
     unsigned long long before = 0;
-    uint32_t nty = (height - 1) / tile_px + 1;
-    (void)nty;
-    // full rows of tiles above: count owned tiles per row analytically would need care at edges;
-    // tiles are few (<= a few thousand), a loop is fine.
-    for (uint32_t q = rank; q < t; q += world)
+    for (uint32_t j = 0;; j++)
     {
+        const uint32_t q = lupin_owned_tile(j, rank, world, ntx);
+        if (q == t) break;
         uint32_t qx = (q % ntx) * tile_px, qy = (q / ntx) * tile_px;
         uint32_t w = min(tile_px, width - qx), h = min(tile_px, height - qy);
         before += (unsigned long long)w * h;

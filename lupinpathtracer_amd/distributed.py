@@ -3,8 +3,8 @@
 The path shards by pixel tiles: every pixel owns its RNG stream (seeded from the GLOBAL pixel index and
 accum_counter, pathtracer.wgsl:224-226) and its output texel, so ranks never exchange anything while
 accumulating.  Tiles (tile_size x 4 pixels, numbered row-major like renderer.rs:816-817) are dealt
-round-robin, rank r owns tiles r, r + world, ... -- interleaved because per-tile cost varies a lot (sky vs
-geometry).  The one exchange step is the gather of per-tile Rgba16Float payloads at readback: one all-gather of
+round-robin, rank r owns tiles r, r + world, ... (rows rotated when that would make column stripes, see
+`owned_tiles`) -- interleaved because per-tile cost varies a lot (sky vs geometry).  The one exchange step is the gather of per-tile Rgba16Float payloads at readback: one all-gather of
 equally sized packed buffers (RCCL over xGMI on the GPU box; gloo in the CPU tests).
 
 `TileDeviceOps` is the seam between this host logic and the device: the product implementation calls the HIP
@@ -21,7 +21,11 @@ def tile_grid(width, height, tile_size):
 
 
 def owned_tiles(width, height, tile_size, rank, world):
+    """include/lupin_tiles.h restated: round-robin over the row-major tile index; when a row holds a multiple of `world`
+    tiles (which would give every rank fixed columns) each row is rotated by one more: owner = (tx + ty) % world."""
     ntx, nty, _ = tile_grid(width, height, tile_size)
+    if world > 1 and ntx % world == 0:
+        return [ty * ntx + tx for ty in range(nty) for tx in range((rank - ty) % world, ntx, world)]
     return list(range(rank, ntx * nty, world))
 
 

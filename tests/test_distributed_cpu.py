@@ -12,7 +12,8 @@ from lupinpathtracer_amd import api, distributed
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("w,h,ts,world", [(1024, 1024, 32, 8), (2048, 1024, 32, 2), (100, 37, 3, 3), (64, 64, 16, 5), (7, 5, 1, 2)])
+@pytest.mark.parametrize("w,h,ts,world", [(1024, 1024, 32, 8), (2048, 1024, 32, 2), (100, 37, 3, 3), (64, 64, 16, 5), (7, 5, 1, 2),
+                                           (1000, 700, 25, 5), (2048, 2048, 8, 4), (90, 50, 5, 3)])
 def test_tile_partition_is_exact(built, w, h, ts, world):
     seen = np.zeros((h, w), np.int32)
     total = 0
@@ -26,6 +27,12 @@ def test_tile_partition_is_exact(built, w, h, ts, world):
         total += px
     assert np.all(seen == 1) and total == w * h
     assert sum(len(distributed.owned_tiles(w, h, ts, r, world)) for r in range(world)) == api.get_num_tiles(ts, w, h)
+    # no rank is confined to fixed columns (rows are rotated when a row holds a multiple of `world` tiles)
+    ntx, nty, _ = distributed.tile_grid(w, h, ts)
+    if nty >= world and ntx >= world:
+        for r in range(world):
+            cols = {t % ntx for t in distributed.owned_tiles(w, h, ts, r, world)}
+            assert len(cols) == ntx, (r, sorted(cols))
 
 
 def test_pack_unpack_round_trip(built):

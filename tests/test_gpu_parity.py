@@ -216,6 +216,22 @@ def test_full_size_properties_cornell_1024(gpu_ctx):
         api.unpack_tiles(gpu_ctx, gathered, ts, r, world, buf.device_ptr())
         gpu_ctx.sync()
     assert util.f16_words_differ(full, gathered.download()) == 0
+    # the same with 16 tiles per row and 4 ranks: a multiple, where ownership rotates row by row (include/lupin_tiles.h)
+    world = 4
+    shards4, gathered4 = api.Texture(gpu_ctx, W, H), api.Texture(gpu_ctx, W, H)
+    for r in range(world):
+        api.pathtrace_scene_tiles(gpu_ctx, res, scene, shards4, 0, desc, ts, r, world)
+    assert util.f16_words_differ(full, shards4.download()) == 0
+    from lupinpathtracer_amd import distributed
+    host = shards4.download()
+    for r in range(world):
+        npx = api.packed_tile_pixels(W, H, ts, r, world)
+        buf = api.Texture(gpu_ctx, npx, 1)
+        assert api.pack_tiles(gpu_ctx, shards4, ts, r, world, buf.device_ptr()) == npx
+        assert np.array_equal(buf.download().reshape(-1, 4).view(np.uint16), distributed.pack_tiles_numpy(host, ts, r, world).view(np.uint16))
+        api.unpack_tiles(gpu_ctx, gathered4, ts, r, world, buf.device_ptr())
+        gpu_ctx.sync()
+    assert util.f16_words_differ(full, gathered4.download()) == 0
     # oracle parity on a band of rows via the reference's own tiling (tile_size 256 groups wide, 2 groups tall)
     band = np.zeros((H, W, 4), np.float16)
     oracle.pathtrace(scene, W, H, cam.params, cam.transform, 8, 8, 0, tile_params=api.TileParams(4, 7 * 64 + 20), out=band)
