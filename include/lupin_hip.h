@@ -403,7 +403,8 @@ int lupin_hip_pathtrace_scene_debug(LupinContext *ctx, const LupinPathtraceResou
 
 /* Tile-sharded variant for multi-GPU rendering (extension; the reference renders tiles one
  * sub-dispatch at a time on one device, renderer.rs:807-829): renders, in ONE wavefront launch,
- * every tile t of the frame with t % world == rank (tiles of tile_size*4 pixels, numbered
+ * every tile t of the frame that lupin_tile_owner(t, tiles_x, world) of include/lupin_tiles.h gives to `rank`
+ * (round-robin t % world; rows rotated when a row holds a multiple of `world` tiles) (tiles of tile_size*4 pixels, numbered
  * row-major as renderer.rs:816-817).  Edge tiles cover all in-bounds pixels, so the union over
  * ranks equals the full-screen dispatch bit for bit.  desc->tile_params is ignored. */
 int lupin_hip_pathtrace_scene_tiles(LupinContext *ctx, const LupinPathtraceResources *res,
@@ -456,7 +457,7 @@ typedef struct LupinTonemapDesc
 int lupin_hip_tonemap_and_fit_aspect(LupinContext *ctx, const LupinTexture *src, uint8_t *dst_rgba8,
                                      uint32_t dst_width, uint32_t dst_height, const LupinTonemapDesc *desc);
 
-/* Tile-sharded multi-GPU support: pack the pixels of every tile t with t % world == rank (tiles
+/* Tile-sharded multi-GPU support: pack the pixels of every tile owned by `rank` (include/lupin_tiles.h) (tiles
  * of tile_size*4 pixels, row-major tile order as renderer.rs:816-817) into a dense device
  * buffer / scatter a packed buffer back. Payload layout: tiles in ascending t, each tile
  * row-major, 8 B per pixel. Returns the number of pixels via out_pixels. */

@@ -723,7 +723,7 @@ def tonemap_and_fit_aspect(ctx, src, dst_width, dst_height, desc=None, dst=None)
 
 
 def pathtrace_scene_tiles(ctx, resources, scene, render_target, pathtrace_type, desc, tile_size, rank, world):
-    """Multi-GPU extension: all tiles t with t % world == rank of one accumulation frame, in one launch."""
+    """Multi-GPU extension: all tiles owned by `rank` (include/lupin_tiles.h: round-robin, rotated rows) of one accumulation frame, in one launch."""
     assert render_target.format() == "Rgba16Float"
     if scene.handle is None:
         raise LupinError(_abi_code("LUPIN_ERR_NO_DEVICE"), "scene was built without a device context; there is no CPU fallback")
