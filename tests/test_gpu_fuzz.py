@@ -208,3 +208,97 @@ def test_frames_in_flight_equal_a_serial_context(seed):
     b = _random_api_mix(1, seed, 600)
     assert a[0] == b[0] and len(a[0]) > 50
     assert util.f16_words_differ(a[1], b[1]) == 0 and util.f16_words_differ(a[2], b[2]) == 0
+
+
+def caterpillar_bvh(verts, indices):
+    """A maximally unbalanced BLAS in the reference's node format: every internal node has one single-triangle leaf and
+    one internal child (the last one two leaves), children adjacent, boxes exact.  n triangles -> depth n - 1."""
+    from lupinpathtracer_amd._abi import BVH_NODE_DTYPE
+    v = np.asarray(verts, np.float32).reshape(-1, 4)[:, :3]
+    idx = np.asarray(indices, np.uint32)
+    tri = v[idx.reshape(-1, 3)]
+    n = len(tri)
+    lo, hi = tri.min(axis=1), tri.max(axis=1)
+    nodes = np.zeros(2 * n - 1, BVH_NODE_DTYPE)
+    suffix_lo = np.minimum.accumulate(lo[::-1], axis=0)[::-1]   # bounds of triangles i..n-1
+    suffix_hi = np.maximum.accumulate(hi[::-1], axis=0)[::-1]
+    cur = 0                                                     # node holding triangles i..n-1
+    for i in range(n - 1):
+        nodes[cur]["aabb_min"], nodes[cur]["aabb_max"] = suffix_lo[i], suffix_hi[i]
+        nodes[cur]["tri_begin_or_first_child"], nodes[cur]["tri_count"] = 2 * i + 1, 0
+        leaf, rest = 2 * i + 1, 2 * i + 2
+        nodes[leaf]["aabb_min"], nodes[leaf]["aabb_max"] = lo[i], hi[i]
+        nodes[leaf]["tri_begin_or_first_child"], nodes[leaf]["tri_count"] = i, 1
+        cur = rest
+    nodes[cur]["aabb_min"], nodes[cur]["aabb_max"] = lo[n - 1], hi[n - 1]
+    nodes[cur]["tri_begin_or_first_child"], nodes[cur]["tri_count"] = n - 1, 1
+    return nodes, idx.copy()
+
+
+def _deep_scene(n_instances):
+    """25 triangles under a depth-24 BLAS (the reference's BVH_MAX_DEPTH - 1), instanced along a line (-> a deep
+    agglomerative TLAS), a box emitter, a constant environment."""
+    rng = np.random.default_rng(9)
+    s = api.SceneCPU()
+    centres = rng.uniform(-0.8, 0.8, (25, 1, 3))
+    tri = (centres + rng.uniform(-0.35, 0.35, (25, 3, 3))).astype(np.float32)
+    s.verts_pos_array.append(pad4(tri.reshape(-1, 3))); s.indices_array.append(np.arange(75, dtype=np.uint32))
+    bv, bi = box_mesh()
+    s.verts_pos_array.append(pad4(bv)); s.indices_array.append(bi)
+    s.mesh_infos = np.array([api.default_mesh_info(), api.default_mesh_info()], MESH_INFO_DTYPE)
+    m0 = api.default_material(); m0["color"] = (0.8, 0.7, 0.6, 1.0)
+    m1 = api.default_material(); m1["mat_type"] = 2; m1["color"] = (0.9, 0.9, 0.9, 1.0); m1["roughness"] = 0.1
+    em = api.default_material(); em["emission"][:3] = (9, 9, 8)
+    s.materials = np.array([m0, m1, em], MATERIAL_DTYPE)
+    insts = []
+    for k in range(n_instances):
+        f = np.zeros((4, 3), np.float32)
+        sc = 0.12 * (1.0 + 0.5 * (k % 3))
+        f[0] = (sc, 0, 0); f[1] = (0, sc, 0); f[2] = (0, 0, sc); f[3] = (-1.6 + 3.2 * k / n_instances, -0.4 + 0.9 * ((k * 7) % 11) / 11.0, 2.0 + 0.004 * k)
+        insts.append(api.instance_from_transform(f, 0, k % 2))
+    f = np.zeros((4, 3), np.float32); f[0] = (0.6, 0, 0); f[1] = (0, 0.6, 0); f[2] = (0, 0, 0.6); f[3] = (0.0, 1.6, 2.5)
+    insts.append(api.instance_from_transform(f, 1, 2))
+    s.instances = np.array(insts, INSTANCE_DTYPE)
+    e = api.default_environment(); e["emission"] = (0.2, 0.25, 0.3)
+    s.environments = np.array([e], ENVIRONMENT_DTYPE)
+    api.validate_scene(s, 0, 0)
+    cam = loader.SceneCamera(transform=np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1], [0, 0.3, -1.5]], np.float32),
+                             params=api.CameraParams(lens=0.03, film=0.036, aspect=1.0, focus=3.0, aperture=0.0))
+    return s, [api.EnvMapInfo(np.ones((1, 1, 4), np.float32), 1, 1)], cam
+
+
+def test_limits_deep_hierarchies_long_paths_odd_sizes(gpu_ctx):
+    """Edges of the input space: a BLAS at the reference's depth cap and a 300-instance TLAS (the LDS traversal stack is
+    sized from the real depths), images that are not multiples of the 4-pixel workgroup down to 1 x 1, many bounces and
+    samples per call (656 iterations in one call), closest hits against the oracle."""
+    from oracle import oracle
+    scene_cpu, envs_info, cam = _deep_scene(n_instances=300)
+    builder = lambda v, i: caterpillar_bvh(v, i) if len(i) == 75 else api.build_bvh(v, i)
+    nodes, _ = caterpillar_bvh(scene_cpu.verts_pos_array[0], scene_cpu.indices_array[0])
+    depth = {0: 0}
+    for i, nd in enumerate(nodes):
+        if nd["tri_count"] == 0:
+            depth[int(nd["tri_begin_or_first_child"])] = depth[int(nd["tri_begin_or_first_child"]) + 1] = depth[i] + 1
+    assert max(depth.values()) == 24        # BVH_MAX_DEPTH - 1 (renderer.rs:296): the deepest tree the reference's 26-entry stack walks
+    scene = api.build_accel_structures_and_upload(gpu_ctx, scene_cpu, [], envs_info, blas_builder=builder)
+    rng = np.random.default_rng(2)
+    n = 6000
+    ori = np.tile(np.array([0.0, 0.3, -1.5], np.float32), (n, 1))
+    d = rng.normal(size=(n, 3)).astype(np.float32) * np.array([0.6, 0.35, 0.0], np.float32) + np.array([0.0, 0.0, 1.0], np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    g, o = api.trace_rays(gpu_ctx, scene, ori, d), oracle.trace_rays(scene, ori, d)
+    assert np.array_equal(g[0], o[0]) and g[0].sum() > 500
+    hit = g[0].astype(bool)
+    for k in (1, 3, 4):
+        assert np.array_equal(np.asarray(g[k])[hit].view(np.uint32), np.asarray(o[k])[hit].view(np.uint32))
+    for (W, H) in ((1, 1), (3, 5), (5, 3), (33, 17)):
+        got = util.gpu_accumulate(gpu_ctx, scene, cam, W, H, frames=2, spp=2, max_bounces=6)
+        ref = util.oracle_accumulate(scene, cam, W, H, frames=2, spp=2, max_bounces=6)
+        assert util.f16_words_differ(got, ref) == 0, (W, H)
+    got = util.gpu_accumulate(gpu_ctx, scene, cam, 24, 16, frames=1, spp=16, max_bounces=40)   # 16 x 41 iterations in one call
+    ref = util.oracle_accumulate(scene, cam, 24, 16, frames=1, spp=16, max_bounces=40)
+    assert util.f16_words_differ(got, ref) == 0
+    for ptype in (1, 3):
+        got = util.gpu_accumulate(gpu_ctx, scene, cam, 20, 12, frames=1, spp=3, max_bounces=12, ptype=ptype)
+        ref = util.oracle_accumulate(scene, cam, 20, 12, frames=1, spp=3, max_bounces=12, ptype=ptype)
+        assert util.f16_words_differ(got, ref) == 0, ptype
