@@ -171,16 +171,19 @@ static int ensure_path_buffers(LupinContext *ctx0, Lane *ctx, uint64_t slots, ui
 }
 
 // depth of a hierarchy in internal levels = worst-case number of parked far children
+// depth of a BLAS in internal levels; UINT32_MAX for a node array that is not a tree (bounded walk, like the TLAS check)
 static uint32_t blas_depth(const LupinBvhNode *nodes, uint32_t count)
 {
     if (count == 0) return 0;
     uint32_t best = 0;
+    uint64_t visited = 0;
     std::vector<std::pair<uint32_t, uint32_t>> st;
     st.push_back({0u, 0u});
     while (!st.empty())
     {
         auto [n, d] = st.back();
         st.pop_back();
+        if (++visited > (uint64_t)count + 1) return 0xFFFFFFFFu;
         if (nodes[n].tri_count == 0)
         {
             best = std::max(best, d + 1);
@@ -590,7 +593,9 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
             blas[ref[n]] = w;
         }
         mesh_root[mi] = ref[0];
-        max_blas_depth = std::max(max_blas_depth, blas_depth(m.bvh_nodes, m.num_bvh_nodes));
+        const uint32_t bd = blas_depth(m.bvh_nodes, m.num_bvh_nodes);
+        if (bd == 0xFFFFFFFFu) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "BLAS is not a tree"); }
+        max_blas_depth = std::max(max_blas_depth, bd);
     }
 
     // ---- TLAS ----

@@ -149,6 +149,23 @@ def test_error_behaviour(gpu_ctx):
         api.build_pathtrace_resources(gpu_ctx, api.BakedPathtraceParams(samples_per_pixel=0))
 
 
+def test_malformed_hierarchies_are_rejected(gpu_ctx):
+    """A node array with a cycle would hang the reference's traversal; scene creation refuses it."""
+    from lupinpathtracer_amd import loader
+    scene_cpu = loader.cornell_box_scene_cpu()[0]
+
+    def cyclic(v, i):
+        nodes, idx = api.build_bvh(v, i)
+        if len(nodes) >= 3:
+            nodes = nodes.copy()
+            inner = [k for k in range(len(nodes)) if nodes[k]["tri_count"] == 0]
+            nodes[inner[-1]]["tri_begin_or_first_child"] = 0        # the deepest internal node points back at the root
+        return nodes, idx
+    with pytest.raises(api.LupinError) as e:
+        api.build_accel_structures_and_upload(gpu_ctx, scene_cpu, [], [], blas_builder=cyclic)
+    assert "not a tree" in str(e.value) or e.value.code == -1
+
+
 def test_empty_scene_and_rne_mode(gpu_ctx):
     from oracle import oracle
     empty = loader.build_scene_empty(gpu_ctx)
