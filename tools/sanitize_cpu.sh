@@ -1,0 +1,35 @@
+#!/bin/bash
+# AddressSanitizer + UBSan over the CPU-side code (GPU sanitizers are not available on the pool): the oracle on several
+# scenes and all integrators, the host builders behind the Python host, the C++ loader.  Run from the repo root.
+set -e
+ASAN=$(gcc -print-file-name=libasan.so); UBSAN=$(gcc -print-file-name=libubsan.so)
+SAN="-fsanitize=address,undefined -fno-omit-frame-pointer -O1 -g -std=c++17"
+g++ $SAN -fPIC -ffp-contract=off -fno-fast-math -fopenmp -shared -o /tmp/liblupin_oracle_asan.so oracle/lupin_oracle.cpp
+g++ $SAN -fPIC -Iinclude -shared lupinpathtracer_amd/csrc/builders.cpp -o /tmp/libbuilders_asan.so
+g++ $SAN -Iinclude tests/loader_dump.cpp -Llupinpathtracer_amd -llupin_hip -L/opt/rocm/lib -Wl,-rpath,$PWD/lupinpathtracer_amd -Wl,-rpath,/opt/rocm/lib -lz -o /tmp/loader_dump_asan
+export ASAN_OPTIONS=detect_leaks=0
+LD_PRELOAD=$ASAN:$UBSAN python3 - <<'PY'
+import os, sys, ctypes as C
+sys.path.insert(0, os.getcwd())
+import numpy as np
+from oracle import oracle
+oracle.LIB_PATH = "/tmp/liblupin_oracle_asan.so"
+from lupinpathtracer_amd import _abi, api, loader
+h = C.CDLL("/tmp/libbuilders_asan.so")
+for name, res, args in _abi.SYMBOLS:
+    if hasattr(h, name):
+        f = getattr(h, name); f.restype = res; f.argtypes = args
+_abi._lib = h
+from tests import util
+for name, cam_i in (("cornellbox_builtin", 0), ("materials4", 1), ("features1", 1), ("environments2", 2), ("furnace2", 0)):
+    scene, cams = util.load_scene(name, None)
+    for ptype in range(4):
+        oracle.pathtrace(scene, 48, 24, cams[cam_i].params, cams[cam_i].transform, 8, 2, ptype, num_threads=4)
+    oracle.pathtrace(scene, 48, 24, cams[cam_i].params, cams[cam_i].transform, 8, 2, falsecolor_type=3)
+    oracle.pathtrace(scene, 48, 24, cams[cam_i].params, cams[cam_i].transform, 8, 2, debug_desc=api.DebugVizDesc(1, 0.0, 50.0, False))
+    print("oracle + builders:", name, "clean", flush=True)
+oracle.tonemap(np.ones((9, 13, 4), np.float16), 31, 17, api.TonemapDesc(viewport=api.Viewport(3, 2, 20, 11), clear=False), dst=np.zeros((17, 31, 4), np.uint8))
+PY
+mkdir -p /tmp/ld_asan
+for n in materials1 features1 environments2 materials4; do /tmp/loader_dump_asan tests/golden/scenes/$n/$n.json tests/golden/scenes/_shared /tmp/ld_asan > /dev/null; echo "C++ loader: $n clean"; done
+echo "sanitizers: no findings"
