@@ -517,8 +517,12 @@ LP_FN float4 sample_texture(const SceneDev &sc, uint32_t tex_idx, float u, float
     float x0f = floorf(x), y0f = floorf(y);
     float fx = x - x0f, fy = y - y0f;
     int x0 = f2i_sat(x0f), y0 = f2i_sat(y0f);
-    int xa = ((x0 % w) + w) % w, ya = ((y0 % h) + h) % h;
-    int xb = (xa + 1) % w, yb = (ya + 1) % h;
+    // Repeat addressing: ((i mod n) + n) mod n.  For power-of-two sizes that is i & (n - 1) for every int (two's complement),
+    // and (a + 1) mod n is a compare: four integer divisions (~40 instructions each on this hardware) saved per lookup.
+    int xa, ya;
+    if ((w & (w - 1)) == 0) xa = x0 & (w - 1); else xa = ((x0 % w) + w) % w;
+    if ((h & (h - 1)) == 0) ya = y0 & (h - 1); else ya = ((y0 % h) + h) % h;
+    int xb = xa + 1 == w ? 0 : xa + 1, yb = ya + 1 == h ? 0 : ya + 1;
     float4 top = lerp_texels(fetch_texel(sc, t, xa, ya), fetch_texel(sc, t, xb, ya), fx);
     float4 bot = lerp_texels(fetch_texel(sc, t, xa, yb), fetch_texel(sc, t, xb, yb), fx);
     return lerp_texels(top, bot, fy);
