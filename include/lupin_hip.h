@@ -277,6 +277,7 @@ typedef struct LupinPathtraceResources LupinPathtraceResources;
 typedef struct LupinScene LupinScene;
 typedef struct LupinTexture LupinTexture;                     /* one Rgba16Float render target */
 typedef struct LupinDoubleBufferedTexture LupinDoubleBufferedTexture;
+typedef struct LupinComm LupinComm;                           /* RCCL communicator of one context (multi-GPU gather) */
 
 /* renderer.rs:644-649 */
 typedef struct LupinAccumulationParams {
@@ -302,7 +303,8 @@ enum LupinStatus {
     LUPIN_ERR_NO_SW_BVH = -4,        /* renderer.rs:774-777 */
     LUPIN_ERR_TILE_OUT_OF_RANGE = -5,/* renderer.rs:814 */
     LUPIN_ERR_SAME_TARGET = -6,      /* render_target == prev_frame, renderer.rs:754-755 */
-    LUPIN_ERR_OUT_OF_MEMORY = -7
+    LUPIN_ERR_OUT_OF_MEMORY = -7,
+    LUPIN_ERR_RCCL = -8              /* librccl missing or a collective failed (multi-GPU gather only) */
 };
 
 /* ------------------------------------------------------------------------------------------
@@ -330,6 +332,14 @@ int lupin_hip_sync(LupinContext *ctx);
 int lupin_hip_set_f16_store_rounding(LupinContext *ctx, int mode);
 
 /* lp::build_pathtrace_resources (renderer.rs:470-642): bakes max_bounces / samples_per_pixel */
+/* pathtracer.wgsl:275-289 accumulates into an Rgba16Float texture: the running mean is re-quantised to f16 every frame
+ * (and stalls once 1/k drops under half an ulp).  LUPIN_ACCUM_F16_RUNNING_AVERAGE reproduces that bit for bit
+ * (default); LUPIN_ACCUM_F32 runs the same recurrence on an f32 shadow of each texture (16 B per pixel, allocated on first
+ * use) and stores the rounded f16 view, so lupin_hip_texture_download_rgba16f keeps working and
+ * lupin_hip_texture_download_rgba32f returns the unquantised mean.  The multi-GPU gather moves the f16 view only. */
+enum LupinAccumulationMode { LUPIN_ACCUM_F16_RUNNING_AVERAGE = 0, LUPIN_ACCUM_F32 = 1 };
+int lupin_hip_set_accumulation_mode(LupinContext *ctx, int mode);
+
 int lupin_hip_build_pathtrace_resources(LupinContext *ctx, const LupinBakedPathtraceParams *params,
                                         LupinPathtraceResources **out_res);
 void lupin_hip_destroy_pathtrace_resources(LupinPathtraceResources *res);
@@ -348,6 +358,8 @@ uint32_t lupin_hip_texture_height(const LupinTexture *tex);
 void *lupin_hip_texture_device_ptr(const LupinTexture *tex);
 int lupin_hip_texture_upload_rgba16f(LupinTexture *tex, const uint16_t *pixels);
 /* readback (loader.rs:1775-1879 download path); synchronises the stream */
+/* (H, W, 4) f32 of the texture's f32 accumulator; fails unless the last frame rendered into it used LUPIN_ACCUM_F32 */
+int lupin_hip_texture_download_rgba32f(const LupinTexture *tex, float *out_pixels);
 int lupin_hip_texture_download_rgba16f(const LupinTexture *tex, uint16_t *out_pixels);
 
 int lupin_hip_dbuf_create(LupinContext *ctx, uint32_t width, uint32_t height,
@@ -421,11 +433,37 @@ typedef struct LupinStats {
     double extend_ms;           /* summed hipEvent duration of those launches (0 unless timing on) */
     double shade_ms;
     double total_ms;            /* whole pathtrace_scene device time (timing on) */
+    /* LUPIN_STATS_WORK_COUNTERS: work done by the tracing kernels in this build's layout, per tracing mode
+     * [0] closest hit of the integrator loop, [1] MIS / Direct shadow rays, [2] light-pdf marching:
+     * internal-node visits (one 64-byte node each), triangle tests (48 bytes), instance entries (64 bytes) */
+    uint64_t node_visits[3];
+    uint64_t tri_tests[3];
+    uint64_t instance_entries[3];
 } LupinStats;
-/* reset + enable/disable per-kernel hipEvent timing (timing adds event records to the stream) */
-int lupin_hip_stats_reset(LupinContext *ctx, int enable_kernel_timing);
+enum LupinStatsMode {
+    LUPIN_STATS_PLAIN = 0,           /* path-bounce / path counters only (always on) */
+    LUPIN_STATS_KERNEL_TIMING = 1,   /* + hipEvents around every extend / shade launch (frames run one at a time) */
+    LUPIN_STATS_WORK_COUNTERS = 2    /* + the work-counting instantiation of the tracing kernels */
+};
+/* reset the counters and choose the mode for the calls that follow */
+int lupin_hip_stats_reset(LupinContext *ctx, int mode);
 /* synchronises, then reports totals since the last reset */
 int lupin_hip_stats_get(LupinContext *ctx, LupinStats *out);
+
+/* Device-to-device copy of `bytes` bytes, `reps` times, on the context's stream: (bytes read + bytes written) / time in
+ * GB/s -- the measured HBM peak that bench.py reports next to the nominal 8 TB/s.  Synchronous. */
+int lupin_hip_measure_copy_bandwidth(LupinContext *ctx, uint64_t bytes, uint32_t reps, double *out_gb_per_s);
+
+/* Which HIP runtime serves this process: the version the library was built against (HIP_VERSION), the version of the
+ * libamdhip64 that is bound, and every distinct libamdhip64 mapped (a PyTorch wheel bundles its own; two in one process
+ * make lupin_hip_create_context fail, and LUPIN_GRAPH=1 additionally requires build and runtime major.minor to agree). */
+typedef struct LupinRuntimeInfo {
+    int32_t  build_hip_version;
+    int32_t  runtime_hip_version;
+    uint32_t num_hip_runtimes_mapped;
+    char     hip_runtime_paths[1012];   /* ';'-separated */
+} LupinRuntimeInfo;
+int lupin_hip_runtime_info(LupinRuntimeInfo *out);
 
 /* Standalone closest-hit probe over a ray batch: the traversal kernel alone
  * (bvh_custom.wgsl:7-110). Host arrays; n rays; outputs hit(0/1), dst, u, v, instance, tri. */
@@ -467,6 +505,40 @@ int lupin_hip_unpack_tiles(LupinContext *ctx, LupinTexture *tex, uint32_t tile_s
                            uint32_t rank, uint32_t world, const void *device_src);
 uint64_t lupin_hip_packed_tile_pixels(uint32_t width, uint32_t height, uint32_t tile_size,
                                       uint32_t rank, uint32_t world);
+/* The scatter after an all-gather in ONE launch: `device_gathered` holds `world` payloads of `capacity_pixels` pixels each
+ * (rank r's at r * capacity_pixels * 8 bytes, padded); every tile NOT owned by `rank` is written into `tex`.  For hosts that
+ * run their own collective; lupin_hip_gather_framebuffer does pack + all-gather + this. */
+int lupin_hip_unpack_gathered_tiles(LupinContext *ctx, LupinTexture *tex, uint32_t tile_size, uint32_t rank, uint32_t world,
+                                    const void *device_gathered, uint64_t capacity_pixels);
+
+/* ---- the one exchange step of tile-sharded rendering: RCCL gather of per-tile framebuffers over xGMI ----
+ * No counterpart in the reference (single device; its TileParams sub-dispatch, renderer.rs:807-829, is what the shards
+ * are made of).  A host renders its tiles with lupin_hip_pathtrace_scene_tiles for any number of accumulation frames
+ * (no communication) and calls lupin_hip_gather_framebuffer once per readback: every rank then holds the whole frame,
+ * bit-identical to the single-GPU render.  librccl is dlopen'ed on first use (LUPIN_RCCL_LIB overrides the name).
+ *
+ * One process per GPU:  rank 0 calls lupin_hip_comm_get_unique_id and hands the 128 bytes to the other ranks by any
+ *                       means (file, socket, MPI); every rank then calls lupin_hip_comm_init_rank.
+ * One process, n GPUs:  lupin_hip_comm_init_all over n contexts (one per device), gathers through
+ *                       lupin_hip_gather_framebuffer_all (the n all-gathers form one RCCL group).
+ * A host that already owns an ncclComm_t for the context's device wraps it with lupin_hip_comm_from_nccl. */
+#define LUPIN_COMM_ID_BYTES 128
+int lupin_hip_comm_get_unique_id(uint8_t *out_id /* LUPIN_COMM_ID_BYTES */);
+int lupin_hip_comm_init_rank(LupinContext *ctx, const uint8_t *id /* LUPIN_COMM_ID_BYTES */, uint32_t rank, uint32_t world,
+                             LupinComm **out_comm);
+int lupin_hip_comm_init_all(LupinContext *const *ctxs, uint32_t n, LupinComm **out_comms /* n entries */);
+int lupin_hip_comm_from_nccl(LupinContext *ctx, void *nccl_comm, uint32_t rank, uint32_t world, LupinComm **out_comm);
+void lupin_hip_comm_destroy(LupinComm *comm);
+uint32_t lupin_hip_comm_rank(const LupinComm *comm);
+uint32_t lupin_hip_comm_world(const LupinComm *comm);
+/* pack this rank's tiles of `tex` -> ncclAllGather -> scatter the other ranks' tiles into `tex`; enqueued on the context's
+ * stream after every frame enqueued so far (asynchronous like pathtrace_scene; download / lupin_hip_sync waits). */
+int lupin_hip_gather_framebuffer(LupinComm *comm, LupinTexture *tex, uint32_t tile_size);
+int lupin_hip_gather_framebuffer_all(LupinComm *const *comms, LupinTexture *const *texs, uint32_t n, uint32_t tile_size);
+/* host-side reductions over the ranks for measurement loops (op 0 = sum, 1 = max); synchronous, and every frame this
+ * rank enqueued has completed when they return, so lupin_hip_comm_barrier brackets a timed region */
+int lupin_hip_comm_allreduce_f64(LupinComm *comm, double *inout, uint32_t n, uint32_t op);
+int lupin_hip_comm_barrier(LupinComm *comm);
 
 /* ------------------------------------------------------------------------------------------
  * CPU-side preprocessing that produces the path's inputs (data_structures.rs:20-641).

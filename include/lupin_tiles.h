@@ -41,4 +41,15 @@ LUPIN_TILES_FN uint32_t lupin_owned_tile(uint32_t j, uint32_t rank, uint32_t wor
     return rank + j * world;
 }
 
+/* inverse of lupin_owned_tile: which of its owner's tiles (row-major enumeration) is tile t */
+LUPIN_TILES_FN uint32_t lupin_owned_index(uint32_t t, uint32_t world, uint32_t tiles_x)
+{
+    if (world > 1u && tiles_x % world == 0u)
+    {
+        const uint32_t per_row = tiles_x / world;
+        return (t / tiles_x) * per_row + (t % tiles_x) / world;   /* the row's owned columns are first, first + world, ... */
+    }
+    return t / world;
+}
+
 #endif /* LUPIN_TILES_H */

@@ -134,7 +134,13 @@ class TonemapDescC(C.Structure):
 
 class StatsC(C.Structure):
     _fields_ = [("path_bounces", C.c_uint64), ("paths", C.c_uint64), ("extend_launches", C.c_uint64),
-                ("extend_ms", C.c_double), ("shade_ms", C.c_double), ("total_ms", C.c_double)]
+                ("extend_ms", C.c_double), ("shade_ms", C.c_double), ("total_ms", C.c_double),
+                ("node_visits", C.c_uint64 * 3), ("tri_tests", C.c_uint64 * 3), ("instance_entries", C.c_uint64 * 3)]
+
+
+class RuntimeInfoC(C.Structure):
+    _fields_ = [("build_hip_version", C.c_int32), ("runtime_hip_version", C.c_int32), ("num_hip_runtimes_mapped", C.c_uint32),
+                ("hip_runtime_paths", C.c_char * 1012)]
 
 
 # every symbol include/lupin_hip.h declares: (name, restype, argtypes)
@@ -148,6 +154,10 @@ SYMBOLS = [
     ("lupin_hip_destroy_context", None, [_P]),
     ("lupin_hip_sync", C.c_int, [_P]),
     ("lupin_hip_set_f16_store_rounding", C.c_int, [_P, C.c_int]),
+    ("lupin_hip_set_accumulation_mode", C.c_int, [_P, C.c_int]),
+    ("lupin_hip_texture_download_rgba32f", C.c_int, [_P, _P]),
+    ("lupin_hip_measure_copy_bandwidth", C.c_int, [_P, C.c_uint64, _U32, C.POINTER(C.c_double)]),
+    ("lupin_hip_runtime_info", C.c_int, [C.POINTER(RuntimeInfoC)]),
     ("lupin_hip_build_pathtrace_resources", C.c_int, [_P, C.POINTER(BakedPathtraceParamsC), _PP]),
     ("lupin_hip_destroy_pathtrace_resources", None, [_P]),
     ("lupin_hip_scene_create", C.c_int, [_P, C.POINTER(SceneDesc), _PP]),
@@ -181,7 +191,19 @@ SYMBOLS = [
     ("lupin_hip_build_bvh_device", C.c_int64, [_P, _P, _U32, _P, _U32, _P, C.c_uint64]),
     ("lupin_hip_pack_tiles", C.c_int, [_P, _P, _U32, _U32, _U32, _P, C.POINTER(C.c_uint64)]),
     ("lupin_hip_unpack_tiles", C.c_int, [_P, _P, _U32, _U32, _U32, _P]),
+    ("lupin_hip_unpack_gathered_tiles", C.c_int, [_P, _P, _U32, _U32, _U32, _P, C.c_uint64]),
     ("lupin_hip_packed_tile_pixels", C.c_uint64, [_U32, _U32, _U32, _U32, _U32]),
+    ("lupin_hip_comm_get_unique_id", C.c_int, [_P]),
+    ("lupin_hip_comm_init_rank", C.c_int, [_P, _P, _U32, _U32, _PP]),
+    ("lupin_hip_comm_init_all", C.c_int, [_PP, _U32, _PP]),
+    ("lupin_hip_comm_from_nccl", C.c_int, [_P, _P, _U32, _U32, _PP]),
+    ("lupin_hip_comm_destroy", None, [_P]),
+    ("lupin_hip_comm_rank", _U32, [_P]),
+    ("lupin_hip_comm_world", _U32, [_P]),
+    ("lupin_hip_gather_framebuffer", C.c_int, [_P, _P, _U32]),
+    ("lupin_hip_gather_framebuffer_all", C.c_int, [_PP, _PP, _U32, _U32]),
+    ("lupin_hip_comm_allreduce_f64", C.c_int, [_P, _P, _U32, _U32]),
+    ("lupin_hip_comm_barrier", C.c_int, [_P]),
     ("lupin_build_bvh", C.c_int64, [_P, _U32, _P, _U32, _P, C.c_uint64]),
     ("lupin_build_tlas", C.c_int64, [_P, _U32, _P, _U32, _P]),
     ("lupin_build_alias_table", C.c_int64, [_P, C.c_uint64, _P]),

@@ -169,13 +169,25 @@ class Context:
         """0 = toward zero (what the reference's goldens show; default), 1 = nearest even."""
         check(lib().lupin_hip_set_f16_store_rounding(self.handle, int(mode)))
 
-    def stats_reset(self, kernel_timing=False):
-        check(lib().lupin_hip_stats_reset(self.handle, 1 if kernel_timing else 0))
+    def stats_reset(self, mode=0):
+        """mode: 0 / False plain counters, 1 / True per-kernel hipEvent timing, 2 work counters of the tracing kernels."""
+        check(lib().lupin_hip_stats_reset(self.handle, int(mode)))
 
     def stats(self):
         s = _abi.StatsC()
         check(lib().lupin_hip_stats_get(self.handle, C.byref(s)))
-        return {k: getattr(s, k) for k, _ in _abi.StatsC._fields_}
+        return {k: (getattr(s, k) if not hasattr(getattr(s, k), "__len__") else [int(v) for v in getattr(s, k)])
+                for k, _ in _abi.StatsC._fields_}
+
+    def set_accumulation_mode(self, mode):
+        """0 = f16 running average (reference-faithful, default), 1 = f32 accumulator per texture (pathtracer.wgsl:275-289)."""
+        check(lib().lupin_hip_set_accumulation_mode(self.handle, int(mode)))
+
+    def measure_copy_bandwidth(self, nbytes=1 << 30, reps=10):
+        """GB/s (read + written) of a device-to-device copy: the measured HBM peak."""
+        out = C.c_double()
+        check(lib().lupin_hip_measure_copy_bandwidth(self.handle, nbytes, reps, C.byref(out)))
+        return float(out.value)
 
     def close(self):
         if self.handle:
@@ -191,6 +203,15 @@ class Context:
 
 def device_count():
     return int(lib().lupin_hip_device_count())
+
+
+def runtime_info():
+    """HIP version the library was built against / runs on, and every libamdhip64 mapped into the process."""
+    r = _abi.RuntimeInfoC()
+    check(lib().lupin_hip_runtime_info(C.byref(r)))
+    paths = r.hip_runtime_paths.decode("utf-8", "replace")
+    return {"build_hip_version": int(r.build_hip_version), "runtime_hip_version": int(r.runtime_hip_version),
+            "num_hip_runtimes_mapped": int(r.num_hip_runtimes_mapped), "hip_runtime_paths": [p for p in paths.split(";") if p]}
 
 
 class PathtraceResources:
@@ -244,6 +265,12 @@ class Texture:
         """(H, W, 4) float16; synchronises (loader.rs download_texture)."""
         out = np.empty((self.height, self.width, 4), dtype=np.float16)
         check(lib().lupin_hip_texture_download_rgba16f(self.handle, ptr(out)))
+        return out
+
+    def download_f32(self):
+        """(H, W, 4) float32 of the f32 accumulator (frames rendered with Context.set_accumulation_mode(1))."""
+        out = np.empty((self.height, self.width, 4), dtype=np.float32)
+        check(lib().lupin_hip_texture_download_rgba32f(self.handle, ptr(out)))
         return out
 
     def __del__(self):
@@ -743,8 +770,74 @@ def unpack_tiles(ctx, texture, tile_size, rank, world, device_src_ptr):
     check(lib().lupin_hip_unpack_tiles(ctx.handle, texture.handle, tile_size, rank, world, C.c_void_p(device_src_ptr)))
 
 
+def unpack_gathered_tiles(ctx, texture, tile_size, rank, world, device_gathered_ptr, capacity_pixels):
+    """One launch: every tile not owned by `rank` from `world` payloads of `capacity_pixels` pixels each."""
+    check(lib().lupin_hip_unpack_gathered_tiles(ctx.handle, texture.handle, tile_size, rank, world, C.c_void_p(device_gathered_ptr), capacity_pixels))
+
+
 def packed_tile_pixels(width, height, tile_size, rank, world):
     return int(lib().lupin_hip_packed_tile_pixels(width, height, tile_size, rank, world))
+
+
+class Comm:
+    """RCCL communicator of one context (include/lupin_hip.h "the one exchange step"): one per rank / per GPU."""
+
+    def __init__(self, ctx, handle, rank, world):
+        self.ctx, self.handle, self.rank, self.world = ctx, handle, rank, world
+
+    @staticmethod
+    def unique_id():
+        """128 opaque bytes made by rank 0 (ncclGetUniqueId) that every rank passes to `init_rank`."""
+        buf = (C.c_uint8 * 128)()
+        check(lib().lupin_hip_comm_get_unique_id(C.cast(buf, C.c_void_p)))
+        return bytes(buf)
+
+    @classmethod
+    def init_rank(cls, ctx, unique_id, rank, world):
+        assert len(unique_id) == 128
+        h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        check(lib().lupin_hip_comm_init_rank(ctx.handle, C.cast(buf, C.c_void_p), rank, world, C.byref(h)))
+        return cls(ctx, h, rank, world)
+
+    @classmethod
+    def init_all(cls, ctxs):
+        """One process driving len(ctxs) GPUs (one context per device)."""
+        n = len(ctxs)
+        cin = (C.c_void_p * n)(*[c.handle for c in ctxs])
+        cout = (C.c_void_p * n)()
+        check(lib().lupin_hip_comm_init_all(cin, n, cout))
+        return [cls(ctxs[i], C.c_void_p(cout[i]), i, n) for i in range(n)]
+
+    def gather_framebuffer(self, texture, tile_size):
+        """pack own tiles -> all-gather -> scatter the others' tiles; enqueued, `texture.download()` / `ctx.sync()` waits."""
+        check(lib().lupin_hip_gather_framebuffer(self.handle, texture.handle, tile_size))
+
+    def allreduce(self, values, op="sum"):
+        a = np.ascontiguousarray(values, dtype=np.float64).copy()
+        check(lib().lupin_hip_comm_allreduce_f64(self.handle, ptr(a), a.size, {"sum": 0, "max": 1}[op]))
+        return a
+
+    def barrier(self):
+        """Every rank's enqueued frames have completed when this returns."""
+        check(lib().lupin_hip_comm_barrier(self.handle))
+
+    def close(self):
+        if self.handle and self.ctx.handle:
+            lib().lupin_hip_comm_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def gather_framebuffer_all(comms, textures, tile_size):
+    n = len(comms)
+    check(lib().lupin_hip_gather_framebuffer_all((C.c_void_p * n)(*[c.handle for c in comms]),
+                                                 (C.c_void_p * n)(*[t.handle for t in textures]), n, tile_size))
 
 
 def _abi_code(name):

@@ -310,6 +310,21 @@ struct GeoCounting
     LP_DEV InstanceDev inst(uint32_t i) const { return base.inst(i); }
 };
 
+// Work accounting of the traversal kernels in THIS build's layout (bench.py's roofline numerator): every internal-node
+// visit fetches one 64-byte WideNode, every triangle test one 48-byte TriVerts, every instance entry one 64-byte record.
+// Same idea as GeoCounting, with the calling thread's own three tallies; the traversal code is untouched.
+template <typename Base>
+struct GeoTally
+{
+    Base base;
+    uint32_t *tally;   // [0] node visits, [1] triangle tests, [2] instance entries
+    static constexpr bool kCounting = false;   // light culling stays on: the tally is of the work actually done
+    LP_DEV NodeRegs node(bool in_blas, uint32_t i) const { tally[0] += 1u; return base.node(in_blas, i); }
+    LP_DEV TriVerts tri(uint32_t i) const { tally[1] += 1u; return base.tri(i); }
+    LP_DEV TriVerts tri_fetch(uint32_t i) const { return base.tri_fetch(i); }
+    LP_DEV InstanceDev inst(uint32_t i) const { tally[2] += 1u; return base.inst(i); }
+};
+
 LP_DEV GeoGlobal geo_global(const SceneDev &sc)
 {
     GeoGlobal g; g.tlas = sc.tlas; g.blas = sc.blas; g.tris = sc.tris; g.instances = sc.instances;

@@ -16,6 +16,7 @@
 #include <atomic>
 
 #include "lupin_stages.hpp"
+#include "lupin_internal.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // Host side
@@ -28,6 +29,7 @@ static int fail(int code, const std::string &msg) { g_last_error = msg; return c
 #define HIP_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return fail(LUPIN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } while (0)
 
 #define LP_MAX_LANES 4
+#define LP_WORK_WORDS 12   // 3 tracing modes (closest hit | shadow rays | light-pdf marching) x {nodes, triangles, instances}, padded
 // "Lanes" (stream + path buffers + counters) let consecutive pathtrace_scene calls overlap: the wavefront of
 // frame k+1 starts while the thin tail of frame k is still draining.  Frames only meet at k_resolve (frame k+1 blends
 // with frame k's output), which waits on the previous call's completion event.
@@ -38,6 +40,7 @@ struct Lane
     uint64_t capacity = 0;          // slots the path buffers hold
     uint32_t counts_capacity = 0;
     unsigned long long *stat_counters = nullptr;   // per shard: [2s] path bounces, [2s+1] paths
+    unsigned long long *work_counters = nullptr;   // [3 * mode + {nodes, triangles, instances}] of the COUNT kernels (stats mode 2)
     hipEvent_t done = nullptr;      // recorded after the last kernel of the lane's latest call
     bool used = false;
     FrameParams *d_fp = nullptr;    // this lane's per-call parameters (k_set_params writes, the stage kernels read)
@@ -64,6 +67,9 @@ struct LupinContext
     int last_lane = -1;
     hipEvent_t marker = nullptr;
     bool timing = false;
+    bool counting = false;          // lupin_hip_stats_reset(ctx, 2): the tracing kernels run their work-counting instantiation
+    int accum_mode = 0;             // LUPIN_ACCUM_F16_RUNNING_AVERAGE | LUPIN_ACCUM_F32
+    int runtime_version = 0;        // hipRuntimeGetVersion of the libamdhip64 this process bound
     int store_rounding = 0;        // LUPIN_STORE_ROUND_TOWARD_ZERO
     bool lds_geometry = true;       // LUPIN_LDS_GEOMETRY=0 keeps small scenes in global memory (A/B runs)
     int persistent_extend = 2;      // LUPIN_EXTEND: "simple" 0 | "persistent" 1 (always) | default 2: persistent for scenes traversed from global memory
@@ -83,13 +89,6 @@ struct LupinPathtraceResources
 {
     LupinContext *ctx;
     LupinBakedPathtraceParams params;
-};
-
-struct LupinTexture
-{
-    LupinContext *ctx;
-    uint32_t width, height;
-    __half *data;
 };
 
 struct LupinDoubleBufferedTexture
@@ -203,7 +202,7 @@ static uint32_t persistent_grid_t(LupinContext *ctx, const LupinScene *scene, si
     if (cached == 0)
     {
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extend_persistent<TYPE, LDSGEO, 0>, LP_BLOCK, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extend_persistent<TYPE, LDSGEO, 0, false>, LP_BLOCK, lds) != hipSuccess || per_cu < 1) per_cu = 1;
         // With frames in flight the persistent tracer of one frame shares the chip with the shading of another: when five
         // or more of its blocks fit per CU, three leave that room and the pair finishes sooner (materials1 / environments1
         // +5 %); deeper scenes fit four at most and are latency-bound, they keep them all (bistro-class -9 % with two).
@@ -234,15 +233,28 @@ static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *sc
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     if (ctx->timing) { e0 = get_event(ctx); e1 = get_event(ctx); e2 = get_event(ctx); hipEventRecord(e0, st); }
     const bool persistent = pblocks != 0;
+    unsigned long long *work = ln->work_counters;
     if (persistent)
-        hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, 0>), dim3(pblocks), dim3(LP_BLOCK), lds, st,
-                           scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words, ctx->node_steps);
+    {
+        if (ctx->counting)
+            hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, 0, true>), dim3(pblocks), dim3(LP_BLOCK), lds, st,
+                               scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words, ctx->node_steps, work);
+        else
+            hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, 0, false>), dim3(pblocks), dim3(LP_BLOCK), lds, st,
+                               scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words, ctx->node_steps, work);
+    }
     else
     {
-        if (scene->all_opaque && ctx->specialize_simple)
-            hipLaunchKernelGGL((k_extend<TYPE, LDSGEO, true>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
+        const bool opaque = scene->all_opaque && ctx->specialize_simple;
+        if (ctx->counting)
+        {
+            if (opaque) hipLaunchKernelGGL((k_extend<TYPE, LDSGEO, true, true>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words, work);
+            else hipLaunchKernelGGL((k_extend<TYPE, LDSGEO, false, true>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words, work);
+        }
+        else if (opaque)
+            hipLaunchKernelGGL((k_extend<TYPE, LDSGEO, true, false>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words, work);
         else
-            hipLaunchKernelGGL((k_extend<TYPE, LDSGEO, false>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
+            hipLaunchKernelGGL((k_extend<TYPE, LDSGEO, false, false>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words, work);
     }
     if (ctx->timing) hipEventRecord(e1, st);
     if (scene->simple_matte && ctx->specialize_simple)
@@ -254,8 +266,12 @@ static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *sc
         if (persistent && ctx->persistent_shadow)
         {
             // large scenes: the shadow rays go through the phase-scheduled persistent tracer as well, then a light finish pass
-            hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, 1>), dim3(pblocks), dim3(LP_BLOCK), lds, st,
-                               scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words, ctx->node_steps);
+            if (ctx->counting)
+                hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, 1, true>), dim3(pblocks), dim3(LP_BLOCK), lds, st,
+                                   scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words, ctx->node_steps, work);
+            else
+                hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, 1, false>), dim3(pblocks), dim3(LP_BLOCK), lds, st,
+                                   scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words, ctx->node_steps, work);
             hipLaunchKernelGGL((k_shadow<TYPE, LDSGEO, true>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, stack_words);
         }
         else
@@ -311,8 +327,24 @@ static hipError_t sync_all(LupinContext *ctx)
     return e;
 }
 
-#include "lupin_internal.hpp"
 int lupin_internal_fail(int code, const char *msg) { return fail(code, msg); }
+void lupin_internal_join_primary(LupinContext *ctx) { join_primary(ctx); }
+int lupin_internal_sync_all(LupinContext *ctx) { HIP_TRY(hipSetDevice(ctx->device)); HIP_TRY(sync_all(ctx)); return LUPIN_OK; }
+// pack / unpack launches on the primary stream, ordered after every frame enqueued so far (see k_tiles_copy for `mode`)
+int lupin_internal_tiles_copy(LupinContext *ctx, const LupinTexture *tex, void *packed, uint32_t tile_size, uint32_t rank, uint32_t world,
+                              uint64_t capacity_px, int mode)
+{
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint32_t tpx = tile_size * LUPIN_WORKGROUP_SIZE;
+    const uint32_t ntx = (tex->width - 1) / tpx + 1, nty = (tex->height - 1) / tpx + 1;
+    const uint32_t blocks = mode == 2 ? ntx * nty : lupin_owned_tile_count(ntx * nty, rank, world);
+    join_primary(ctx);
+    if (blocks)
+        hipLaunchKernelGGL(k_tiles_copy, dim3(blocks), dim3(LP_BLOCK), 0, ctx->stream, (uint2 *)tex->data, (uint2 *)packed, tex->width, tex->height,
+                           tpx, rank, world, (unsigned long long)capacity_px, mode);
+    HIP_TRY(hipGetLastError());
+    return LUPIN_OK;
+}
 int lupin_internal_ctx_device(const LupinContext *ctx) { return ctx->device; }
 hipStream_t lupin_internal_ctx_stream(const LupinContext *ctx) { return ctx->stream; }
 
@@ -334,8 +366,14 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
     if (n <= 0) return fail(LUPIN_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
     if (device_ordinal < 0 || device_ordinal >= n) return fail(LUPIN_ERR_INVALID_ARGUMENT, "device ordinal out of range");
     HIP_TRY(hipSetDevice(device_ordinal));
+    LupinRuntimeInfo ri;
+    lupin_hip_runtime_info(&ri);
+    if (ri.num_hip_runtimes_mapped > 1)
+        return fail(LUPIN_ERR_HIP, std::string("two HIP runtimes are mapped into this process (") + ri.hip_runtime_paths +
+                                   "): load liblupin_hip.so in a process that has not imported another copy (e.g. a PyTorch wheel's)");
     LupinContext *ctx = new LupinContext();
     ctx->device = device_ordinal;
+    ctx->runtime_version = ri.runtime_hip_version;
     hipError_t e = hipSuccess;
     const char *ov = getenv("LUPIN_OVERLAP");
     const char *nl = getenv("LUPIN_LANES");
@@ -349,6 +387,8 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
         if (e == hipSuccess) e = hipMalloc((void **)&ln.d_fp, sizeof(FrameParams));
         if (e == hipSuccess) e = hipMalloc((void **)&ln.stat_counters, 2 * LP_SHARDS * sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMemsetAsync(ln.stat_counters, 0, 2 * LP_SHARDS * sizeof(unsigned long long), ln.stream);
+        if (e == hipSuccess) e = hipMalloc((void **)&ln.work_counters, LP_WORK_WORDS * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMemsetAsync(ln.work_counters, 0, LP_WORK_WORDS * sizeof(unsigned long long), ln.stream);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->marker, hipEventDisableTiming);
     if (e != hipSuccess) { delete ctx; return fail(LUPIN_ERR_HIP, std::string("context setup: ") + hipGetErrorString(e)); }
@@ -369,6 +409,14 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
     if (ssh && strcmp(ssh, "0") == 0) ctx->specialize_simple = false;
     const char *gr = getenv("LUPIN_GRAPH");
     if (gr) ctx->use_graph = strcmp(gr, "0") != 0;
+    if (ctx->use_graph && ctx->runtime_version / 100000 != HIP_VERSION / 100000)
+    {
+        // Graph replay is validated on the runtime this library was built against (HIP_VERSION major.minor).  Round 1 saw a
+        // memory fault on replay when a PyTorch wheel's older libamdhip64 served the process: refuse rather than risk it.
+        delete ctx;
+        return fail(LUPIN_ERR_HIP, "LUPIN_GRAPH=1 needs the HIP runtime this library was built against (built " + std::to_string(HIP_VERSION) +
+                                   ", running on " + std::to_string(ri.runtime_hip_version) + ")");
+    }
     const char *shd = getenv("LUPIN_SHADOW");
     if (shd && strcmp(shd, "simple") == 0) ctx->persistent_shadow = false;
     const char *ns = getenv("LUPIN_NODE_STEPS");
@@ -389,7 +437,7 @@ void lupin_hip_destroy_context(LupinContext *ctx)
         PathBuffers &pb = ctx->lanes[k].pb;
         void *ptrs[] = {pb.ori_rng, pb.dir_meta, pb.weight, pb.radiance, pb.color, pb.hit, pb.hit_tri, pb.vol0, pb.vol1,
                         pb.next_hit, pb.next_tri, pb.queue[0], pb.queue[1], pb.counts, ctx->lanes[k].stat_counters,
-                        pb.sh_org, pb.sh_d0, pb.sh_f0, pb.sh_d1, pb.sh_f1, pb.sh_hit1};
+                        pb.sh_org, pb.sh_d0, pb.sh_f0, pb.sh_d1, pb.sh_f1, pb.sh_hit1, ctx->lanes[k].work_counters};
         for (void *p : ptrs) if (p) hipFree(p);
         if (ctx->lanes[k].done) hipEventDestroy(ctx->lanes[k].done);
         if (ctx->lanes[k].graph_exec) hipGraphExecDestroy(ctx->lanes[k].graph_exec);
@@ -417,6 +465,13 @@ int lupin_hip_set_f16_store_rounding(LupinContext *ctx, int mode)
 {
     if (!ctx || (mode != 0 && mode != 1)) return fail(LUPIN_ERR_INVALID_ARGUMENT, "mode must be 0 (toward zero) or 1 (nearest even)");
     ctx->store_rounding = mode;
+    return LUPIN_OK;
+}
+
+int lupin_hip_set_accumulation_mode(LupinContext *ctx, int mode)
+{
+    if (!ctx || (mode != LUPIN_ACCUM_F16_RUNNING_AVERAGE && mode != LUPIN_ACCUM_F32)) return fail(LUPIN_ERR_INVALID_ARGUMENT, "unknown accumulation mode");
+    ctx->accum_mode = mode;
     return LUPIN_OK;
 }
 
@@ -836,7 +891,7 @@ int lupin_hip_texture_create(LupinContext *ctx, uint32_t width, uint32_t height,
     if (!ctx || !out_tex || width == 0 || height == 0) return fail(LUPIN_ERR_INVALID_ARGUMENT, "bad texture size");
     HIP_TRY(hipSetDevice(ctx->device));
     LupinTexture *t = new LupinTexture();
-    t->ctx = ctx; t->width = width; t->height = height; t->data = nullptr;
+    t->ctx = ctx; t->width = width; t->height = height; t->data = nullptr; t->accum32 = nullptr; t->accum32_valid = false;
     size_t bytes = (size_t)width * height * 4 * sizeof(__half);
     hipError_t e = hipMalloc((void **)&t->data, bytes);
     if (e != hipSuccess) { delete t; return fail(LUPIN_ERR_OUT_OF_MEMORY, hipGetErrorString(e)); }
@@ -850,6 +905,7 @@ void lupin_hip_texture_destroy(LupinTexture *tex)
     hipSetDevice(tex->ctx->device);
     sync_all(tex->ctx);
     hipFree(tex->data);
+    if (tex->accum32) hipFree(tex->accum32);
     delete tex;
 }
 uint32_t lupin_hip_texture_width(const LupinTexture *tex) { return tex ? tex->width : 0; }
@@ -862,6 +918,17 @@ int lupin_hip_texture_upload_rgba16f(LupinTexture *tex, const uint16_t *pixels)
     HIP_TRY(hipSetDevice(tex->ctx->device));
     join_primary(tex->ctx);
     HIP_TRY(hipMemcpyAsync(tex->data, pixels, (size_t)tex->width * tex->height * 8, hipMemcpyHostToDevice, tex->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(tex->ctx->stream));
+    tex->accum32_valid = false;   // the f16 texels are now the only truth
+    return LUPIN_OK;
+}
+int lupin_hip_texture_download_rgba32f(const LupinTexture *tex, float *out_pixels)
+{
+    if (!tex || !out_pixels) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
+    if (!tex->accum32 || !tex->accum32_valid) return fail(LUPIN_ERR_INVALID_ARGUMENT, "texture has no f32 accumulator (render into it with LUPIN_ACCUM_F32 first)");
+    HIP_TRY(hipSetDevice(tex->ctx->device));
+    join_primary(tex->ctx);
+    HIP_TRY(hipMemcpyAsync(out_pixels, tex->accum32, (size_t)tex->width * tex->height * 16, hipMemcpyDeviceToHost, tex->ctx->stream));
     HIP_TRY(hipStreamSynchronize(tex->ctx->stream));
     return LUPIN_OK;
 }
@@ -902,6 +969,13 @@ int lupin_hip_dbuf_copy_front_to_back(LupinDoubleBufferedTexture *t)
     HIP_TRY(hipSetDevice(t->ctx->device));
     join_primary(t->ctx);
     HIP_TRY(hipMemcpyAsync(b->data, f->data, (size_t)f->width * f->height * 8, hipMemcpyDeviceToDevice, t->ctx->stream));
+    b->accum32_valid = false;
+    if (f->accum32 && f->accum32_valid)
+    {
+        if (!b->accum32) HIP_TRY(hipMalloc((void **)&b->accum32, (size_t)f->width * f->height * 16));
+        HIP_TRY(hipMemcpyAsync(b->accum32, f->accum32, (size_t)f->width * f->height * 16, hipMemcpyDeviceToDevice, t->ctx->stream));
+        b->accum32_valid = true;
+    }
     return LUPIN_OK;
 }
 void lupin_hip_dbuf_flip(LupinDoubleBufferedTexture *t) { if (t) std::swap(t->front_idx, t->back_idx); }
@@ -1020,6 +1094,7 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
         const size_t flds_bytes = (size_t)fstack_words * sizeof(uint32_t) + (flds ? (size_t)scene->dev.geo_blob_words * 16 : 0);
         if (flds_bytes > 160 * 1024) return fail(LUPIN_ERR_INVALID_ARGUMENT, "BVH too deep for the LDS traversal stack");
         const __half *pv = prev ? prev->data : (const __half *)nullptr;
+        render_target->accum32_valid = false;
         join_primary(ctx);
         if (debug)
         {
@@ -1057,7 +1132,7 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
 
     const uint32_t pblocks = persistent_grid(ctx, scene, pathtrace_type, lds_geo, lds);
     hipLaunchKernelGGL(k_set_params, dim3(1), dim3(1), 0, st, fp, ln->d_fp);
-    if (ctx->use_graph && !ctx->timing)
+    if (ctx->use_graph && !ctx->timing && !ctx->counting)
     {
         // Everything between k_set_params and the resolve depends on the call only through *d_fp, so it is captured once per
         // (scene, dispatch size, integrator, buffers) and replayed: one graph launch instead of 2-4 launches per iteration.
@@ -1104,8 +1179,21 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
     }
     if (ctx->last_lane >= 0 && ctx->last_lane != w)
         HIP_TRY(hipStreamWaitEvent(st, ctx->lanes[ctx->last_lane].done, 0));
+    const float4 *prev32 = nullptr;
+    float4 *out32 = nullptr;
+    if (ctx->accum_mode == LUPIN_ACCUM_F32)
+    {
+        if (!render_target->accum32)
+        {
+            HIP_TRY(hipMalloc((void **)&render_target->accum32, (size_t)W * H * 16));
+            HIP_TRY(hipMemsetAsync(render_target->accum32, 0, (size_t)W * H * 16, st));
+        }
+        out32 = render_target->accum32;
+        if (prev && prev->accum32 && prev->accum32_valid) prev32 = prev->accum32;
+    }
+    render_target->accum32_valid = out32 != nullptr;
     hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(LP_BLOCK), 0, st, fp, ln->pb, n,
-                       prev ? prev->data : (const __half *)nullptr, render_target->data);
+                       prev ? prev->data : (const __half *)nullptr, render_target->data, prev32, out32);
     HIP_TRY(hipEventRecord(ln->done, st));
     ln->used = true;
     ctx->last_lane = w;
@@ -1157,7 +1245,10 @@ int lupin_hip_stats_reset(LupinContext *ctx, int enable_kernel_timing)
     ctx->ev_shade.clear();
     for (auto &p : ctx->ev_total) { ctx->ev_pool.push_back(p.first); ctx->ev_pool.push_back(p.second); }
     ctx->ev_total.clear();
-    ctx->timing = enable_kernel_timing != 0;
+    for (int k = 0; k < ctx->num_lanes; k++)
+        HIP_TRY(hipMemsetAsync(ctx->lanes[k].work_counters, 0, LP_WORK_WORDS * sizeof(unsigned long long), ctx->lanes[k].stream));
+    ctx->timing = enable_kernel_timing == LUPIN_STATS_KERNEL_TIMING;
+    ctx->counting = enable_kernel_timing == LUPIN_STATS_WORK_COUNTERS;
     ctx->extend_launches = 0;
     return LUPIN_OK;
 }
@@ -1174,6 +1265,12 @@ int lupin_hip_stats_get(LupinContext *ctx, LupinStats *out)
         HIP_TRY(hipMemcpy(c.data(), ctx->lanes[l].stat_counters, c.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         for (uint32_t k = 0; k < LP_SHARDS; k++) { out->path_bounces += c[2 * k]; out->paths += c[2 * k + 1]; }
     }
+    for (int l = 0; l < ctx->num_lanes; l++)
+    {
+        unsigned long long w[LP_WORK_WORDS];
+        HIP_TRY(hipMemcpy(w, ctx->lanes[l].work_counters, sizeof(w), hipMemcpyDeviceToHost));
+        for (int m = 0; m < 3; m++) { out->node_visits[m] += w[3 * m + 0]; out->tri_tests[m] += w[3 * m + 1]; out->instance_entries[m] += w[3 * m + 2]; }
+    }
     out->extend_launches = ctx->extend_launches;
     auto sum = [](const std::vector<std::pair<hipEvent_t, hipEvent_t>> &v) {
         double ms = 0.0;
@@ -1183,6 +1280,64 @@ int lupin_hip_stats_get(LupinContext *ctx, LupinStats *out)
     out->extend_ms = sum(ctx->ev_extend);
     out->shade_ms = sum(ctx->ev_shade);
     out->total_ms = sum(ctx->ev_total);
+    return LUPIN_OK;
+}
+
+int lupin_hip_measure_copy_bandwidth(LupinContext *ctx, uint64_t bytes, uint32_t reps, double *out_gb_per_s)
+{
+    if (!ctx || !out_gb_per_s || bytes < 16 || reps == 0) return fail(LUPIN_ERR_INVALID_ARGUMENT, "bad copy-bandwidth arguments");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(sync_all(ctx));
+    const size_t n = bytes / 16;
+    float4 *a = nullptr, *b = nullptr;
+    hipError_t e = hipMalloc((void **)&a, n * 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&b, n * 16);
+    if (e != hipSuccess) { if (a) hipFree(a); return fail(LUPIN_ERR_OUT_OF_MEMORY, hipGetErrorString(e)); }
+    hipEvent_t e0 = get_event(ctx), e1 = get_event(ctx);
+    HIP_TRY(hipMemsetAsync(a, 0x3C, n * 16, ctx->stream));
+    const uint32_t blocks = ctx->num_cus * 8;
+    hipLaunchKernelGGL(k_copy_bw, dim3(blocks), dim3(LP_BLOCK), 0, ctx->stream, (const float4 *)a, b, n);   // warm-up: pages touched
+    HIP_TRY(hipEventRecord(e0, ctx->stream));
+    for (uint32_t r = 0; r < reps; r++)
+        hipLaunchKernelGGL(k_copy_bw, dim3(blocks), dim3(LP_BLOCK), 0, ctx->stream, (const float4 *)((r & 1) ? b : a), (r & 1) ? a : b, n);
+    HIP_TRY(hipEventRecord(e1, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    ctx->ev_pool.push_back(e0); ctx->ev_pool.push_back(e1);
+    hipFree(a); hipFree(b);
+    *out_gb_per_s = ms > 0.0f ? 2.0 * (double)(n * 16) * reps / (ms * 1e-3) / 1e9 : 0.0;   // bytes read + bytes written
+    return LUPIN_OK;
+}
+
+int lupin_hip_runtime_info(LupinRuntimeInfo *out)
+{
+    if (!out) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
+    memset(out, 0, sizeof(*out));
+    out->build_hip_version = HIP_VERSION;
+    int v = 0;
+    if (hipRuntimeGetVersion(&v) == hipSuccess) out->runtime_hip_version = v;
+    // every distinct libamdhip64 mapped into this process (a PyTorch wheel bundles its own copy)
+    std::vector<std::string> libs;
+    if (FILE *f = fopen("/proc/self/maps", "r"))
+    {
+        char line[4096];
+        while (fgets(line, sizeof(line), f))
+        {
+            const char *p = strstr(line, "libamdhip64");
+            if (!p) continue;
+            const char *path = strchr(line, '/');
+            if (!path) continue;
+            std::string sp(path);
+            while (!sp.empty() && (sp.back() == '\n' || sp.back() == ' ')) sp.pop_back();
+            if (std::find(libs.begin(), libs.end(), sp) == libs.end()) libs.push_back(sp);
+        }
+        fclose(f);
+    }
+    out->num_hip_runtimes_mapped = (uint32_t)libs.size();
+    std::string joined;
+    for (auto &l : libs) { if (!joined.empty()) joined += ";"; joined += l; }
+    strncpy(out->hip_runtime_paths, joined.c_str(), sizeof(out->hip_runtime_paths) - 1);
     return LUPIN_OK;
 }
 
@@ -1237,13 +1392,7 @@ int lupin_hip_detmath_probe(LupinContext *ctx, int fn, uint32_t n, const float *
 static int pack_common(LupinContext *ctx, const LupinTexture *tex, uint32_t tile_size, uint32_t rank, uint32_t world, void *packed, int unpack)
 {
     if (!ctx || !tex || !packed || tile_size == 0 || world == 0 || rank >= world) return fail(LUPIN_ERR_INVALID_ARGUMENT, "bad pack arguments");
-    HIP_TRY(hipSetDevice(ctx->device));
-    dim3 block(LP_BLOCK, 1, 1), grid((tex->width + LP_BLOCK - 1) / LP_BLOCK, tex->height, 1);
-    join_primary(ctx);
-    hipLaunchKernelGGL(k_pack_tiles, grid, block, 0, ctx->stream, (const uint2 *)tex->data, (uint2 *)packed, tex->width, tex->height,
-                       tile_size * LUPIN_WORKGROUP_SIZE, rank, world, unpack);
-    HIP_TRY(hipGetLastError());
-    return LUPIN_OK;
+    return lupin_internal_tiles_copy(ctx, tex, packed, tile_size, rank, world, 0, unpack ? 1 : 0);
 }
 int lupin_hip_pack_tiles(LupinContext *ctx, const LupinTexture *tex, uint32_t tile_size, uint32_t rank, uint32_t world, void *device_dst, uint64_t *out_pixels)
 {
@@ -1254,6 +1403,13 @@ int lupin_hip_pack_tiles(LupinContext *ctx, const LupinTexture *tex, uint32_t ti
 int lupin_hip_unpack_tiles(LupinContext *ctx, LupinTexture *tex, uint32_t tile_size, uint32_t rank, uint32_t world, const void *device_src)
 {
     return pack_common(ctx, tex, tile_size, rank, world, const_cast<void *>(device_src), 1);
+}
+
+int lupin_hip_unpack_gathered_tiles(LupinContext *ctx, LupinTexture *tex, uint32_t tile_size, uint32_t rank, uint32_t world,
+                                    const void *device_gathered, uint64_t capacity_pixels)
+{
+    if (!ctx || !tex || !device_gathered || tile_size == 0 || world == 0 || rank >= world) return fail(LUPIN_ERR_INVALID_ARGUMENT, "bad unpack arguments");
+    return lupin_internal_tiles_copy(ctx, tex, const_cast<void *>(device_gathered), tile_size, rank, world, capacity_pixels, 2);
 }
 
 int lupin_hip_tonemap_and_fit_aspect(LupinContext *ctx, const LupinTexture *src, uint8_t *dst_rgba8, uint32_t dst_width, uint32_t dst_height,

@@ -258,39 +258,66 @@ __device__ __forceinline__ void trace_alpha(const Geo &geo, const SceneDev &sc, 
     hit_tri = c.tri;
 }
 
-template <int TYPE, bool LDSGEO, bool OPAQUE>
+// Work counters (bench.py's roofline numerator, lupin_hip_stats_reset(ctx, 2)): the COUNT instantiations of the tracing
+// kernels wrap their geometry accessor in GeoTally and add the wave's totals to work[3 * mode + {0 nodes, 1 triangles, 2 instances}].
+// All 64 lanes must be active when this is called.
+__device__ __forceinline__ void tally_flush(const uint32_t (&tally)[3], unsigned long long *work)
+{
+    #pragma unroll
+    for (int k = 0; k < 3; k++)
+    {
+        uint32_t v = tally[k];
+        #pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if ((threadIdx.x & 63u) == 0u && v) atomicAdd(&work[k], (unsigned long long)v);
+    }
+}
+template <typename Geo, bool COUNT> struct TallyOf { typedef Geo type; };
+template <typename Geo> struct TallyOf<Geo, true> { typedef GeoTally<Geo> type; };
+template <bool COUNT, typename Geo>
+__device__ __forceinline__ typename TallyOf<Geo, COUNT>::type with_tally(const Geo &geo, uint32_t *tally)
+{
+    if constexpr (COUNT) { GeoTally<Geo> g; g.base = geo; g.tally = tally; return g; }
+    else return geo;
+}
+
+template <int TYPE, bool LDSGEO, bool OPAQUE, bool COUNT>
 __global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launch_bounds__(LP_BLOCK) k_extend(SceneDev sc, const FrameParams *__restrict__ fpp, PathBuffers pb, uint32_t iter,
-                                                     unsigned long long *shard_stats, uint32_t stack_words)
+                                                     unsigned long long *shard_stats, uint32_t stack_words, unsigned long long *work)
 {
     const FrameParams fp = *fpp;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
-    const auto geo = make_geo<LDSGEO>(sc, lds_stack, stack_words);
+    const auto base_geo = make_geo<LDSGEO>(sc, lds_stack, stack_words);
+    uint32_t tally[3] = {0u, 0u, 0u};
+    const auto geo = with_tally<COUNT>(base_geo, tally);
     const uint32_t shard = blockIdx.x % LP_SHARDS;
     const uint32_t count = pb.counts[iter * LP_SHARDS + shard];
     const uint32_t i = (blockIdx.x / LP_SHARDS) * LP_BLOCK + threadIdx.x;
     if (i == 0 && count) shard_stats[shard * 2 + 0] += count;   // one writer per shard per launch: no atomic needed
-    if (i >= count) return;
-    const uint32_t slot = pb.queue[iter & 1][(size_t)shard * pb.shard_cap + i];
-
-    float4 orr = pb.ori_rng[slot];
-    float4 dm = pb.dir_meta[slot];
-    if (TYPE == LUPIN_PATHTRACE_MIS)
+    if (!COUNT && i >= count) return;
+    if (i < count)
     {
-        if (!(__float_as_uint(dm.w) & META_NEXT_EMISSION))
+        const uint32_t slot = pb.queue[iter & 1][(size_t)shard * pb.shard_cap + i];
+        float4 orr = pb.ori_rng[slot];
+        float4 dm = pb.dir_meta[slot];
+        if (TYPE == LUPIN_PATHTRACE_MIS && !(__float_as_uint(dm.w) & META_NEXT_EMISSION))
         {
             pb.hit[slot] = pb.next_hit[slot];
             pb.hit_tri[slot] = pb.next_tri[slot];
-            return;
+        }
+        else
+        {
+            uint32_t rng = __float_as_uint(orr.w);
+            const uint32_t rng_in = rng;
+            float4 hitrec;
+            uint32_t hit_tri;
+            trace_alpha<typename TallyOf<typename GeoOf<LDSGEO>::type, COUNT>::type, OPAQUE>(geo, sc, lds_stack, mk3(orr.x, orr.y, orr.z), mk3(dm.x, dm.y, dm.z), rng, fp.pc.ray_epsilon, hitrec, hit_tri);
+            pb.hit[slot] = hitrec;
+            pb.hit_tri[slot] = hit_tri;
+            if (rng != rng_in) pb.ori_rng[slot].w = __uint_as_float(rng);
         }
     }
-    uint32_t rng = __float_as_uint(orr.w);
-    const uint32_t rng_in = rng;
-    float4 hitrec;
-    uint32_t hit_tri;
-    trace_alpha<typename GeoOf<LDSGEO>::type, OPAQUE>(geo, sc, lds_stack, mk3(orr.x, orr.y, orr.z), mk3(dm.x, dm.y, dm.z), rng, fp.pc.ray_epsilon, hitrec, hit_tri);
-    pb.hit[slot] = hitrec;
-    pb.hit_tri[slot] = hit_tri;
-    if (rng != rng_in) pb.ori_rng[slot].w = __uint_as_float(rng);
+    if (COUNT) tally_flush(tally, work);
 }
 
 // Persistent, phase-scheduled form of k_extend -- the default for scenes traversed from global memory.  Rays of one
@@ -309,13 +336,16 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launc
 // MODE 1: the shadow rays k_shade recorded for MIS / Direct (two jobs per queue entry, plain closest hit); their hits go
 //         to next_hit / next_tri (MIS ray 0, which doubles as the next vertex) or sh_hit1 / sh_f1.w, and
 //         k_shadow<.., PRETRACED> folds them into the radiance.
-template <int TYPE, bool LDSGEO, int MODE>
+template <int TYPE, bool LDSGEO, int MODE, bool COUNT>
 __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, const FrameParams *__restrict__ fpp, PathBuffers pb, uint32_t iter,
-                                                                unsigned long long *shard_stats, uint32_t refill_min, uint32_t stack_words, uint32_t nsteps)
+                                                                unsigned long long *shard_stats, uint32_t refill_min, uint32_t stack_words, uint32_t nsteps,
+                                                                unsigned long long *work)
 {
     const FrameParams fp = *fpp;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
-    const auto geo = make_geo<LDSGEO>(sc, lds_stack, stack_words);
+    const auto base_geo = make_geo<LDSGEO>(sc, lds_stack, stack_words);
+    uint32_t tally[3] = {0u, 0u, 0u};
+    const auto geo = with_tally<COUNT>(base_geo, tally);
     static_assert(LP_SHARDS <= LP_BLOCK && 256 % LP_SHARDS == 0, "block 0 books one shard per thread; 64-block grids hold whole waves per shard");
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t *counts = pb.counts + (size_t)iter * LP_SHARDS;
@@ -527,6 +557,7 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
             }
         }
     }
+    if (COUNT) tally_flush(tally, work + 3 * MODE);   // the loop ends wave-uniformly: all lanes are here
 }
 
 // clamp_radiance (pathtracer.wgsl:1774-1783)
@@ -1008,9 +1039,31 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launc
     queue_append(alive, slot, pb.queue[(iter + 1) & 1] + (size_t)shard * pb.shard_cap, &pb.counts[(iter + 1) * LP_SHARDS + shard]);
 }
 
-// pathtrace_main tail (pathtracer.wgsl:275-289)
+// pathtrace_main tail (pathtracer.wgsl:275-289): /spp, max(0), progressive blend with prev_frame, Rgba16Float store.
+// Accumulation modes (lupin_hip_set_accumulation_mode):
+//   F16 running average (reference-faithful): prev_frame is the f16 texel the previous call stored, so the running mean
+//       is re-quantised every frame (SURVEY 7 "f16 accumulation semantics");
+//   F32: the same recurrence on an f32 shadow of the textures (prev32 / out32, one float4 per pixel); the f16 texel
+//       is the rounded view of it.  A prev_frame without a shadow (uploaded, or rendered in the other mode) is read as f16.
+// Four channels leave as one 8-byte store.
+__device__ __forceinline__ uint32_t f16_bits(float v, bool rne)
+{
+    return (uint32_t)__half_as_ushort(rne ? __float2half_rn(v) : __float2half_rz(v));
+}
+__device__ __forceinline__ void store_rgba16f(__half *out, size_t pixel, f3 c, bool rne)
+{
+    uint2 w;
+    w.x = f16_bits(c.x, rne) | (f16_bits(c.y, rne) << 16);
+    w.y = f16_bits(c.z, rne) | (0x3C00u << 16);   // alpha = 1.0
+    reinterpret_cast<uint2 *>(out)[pixel] = w;
+}
+__device__ __forceinline__ f3 load_rgb16f(const __half *tex, size_t pixel)
+{
+    const uint2 w = reinterpret_cast<const uint2 *>(tex)[pixel];
+    return mk3(half_bits_to_float(w.x & 0xFFFFu), half_bits_to_float(w.x >> 16), half_bits_to_float(w.y & 0xFFFFu));
+}
 __global__ void __launch_bounds__(LP_BLOCK) k_resolve(FrameParams fp, PathBuffers pb, uint32_t n,
-                                                      const __half *prev, __half *out)
+                                                      const __half *prev, __half *out, const float4 *prev32, float4 *out32)
 {
     uint32_t slot = blockIdx.x * LP_BLOCK + threadIdx.x;
     if (slot >= n) return;
@@ -1020,26 +1073,24 @@ __global__ void __launch_bounds__(LP_BLOCK) k_resolve(FrameParams fp, PathBuffer
     float4 c4 = pb.color[slot];
     float spp = (float)fp.spp;
     f3 c = mk3(maxf(c4.x / spp, 0.0f), maxf(c4.y / spp, 0.0f), maxf(c4.z / spp, 0.0f));
-    size_t px = ((size_t)gy * fp.width + gx) * 4;
+    const size_t px = (size_t)gy * fp.width + gx;
     if (fp.pc.accum_counter != 0)
     {
         float w = 1.0f / (float)fp.pc.accum_counter;
-        f3 pc = mk3(__half2float(prev[px + 0]), __half2float(prev[px + 1]), __half2float(prev[px + 2]));
+        f3 pc;
+        if (prev32) { const float4 p = prev32[px]; pc = mk3(p.x, p.y, p.z); }
+        else pc = load_rgb16f(prev, px);
         c = mk3(maxf(pc.x * (1.0f - w) + c.x * w, 0.0f), maxf(pc.y * (1.0f - w) + c.y * w, 0.0f), maxf(pc.z * (1.0f - w) + c.z * w, 0.0f));
     }
-    if (fp.store_rne)
-    {
-        out[px + 0] = __float2half_rn(c.x);
-        out[px + 1] = __float2half_rn(c.y);
-        out[px + 2] = __float2half_rn(c.z);
-    }
-    else
-    {
-        out[px + 0] = __float2half_rz(c.x);
-        out[px + 1] = __float2half_rz(c.y);
-        out[px + 2] = __float2half_rz(c.z);
-    }
-    out[px + 3] = __float2half_rn(1.0f);
+    if (out32) out32[px] = make_float4(c.x, c.y, c.z, 1.0f);
+    store_rgba16f(out, px, c, fp.store_rne != 0);
+}
+
+// device-to-device copy: the measured HBM peak bench.py reports next to the nominal one
+__global__ void __launch_bounds__(LP_BLOCK) k_copy_bw(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * LP_BLOCK;
+    for (size_t i = (size_t)blockIdx.x * LP_BLOCK + threadIdx.x; i < n; i += stride) dst[i] = src[i];
 }
 
 // pathtrace_falsecolor_main (pathtracer.wgsl:296-452): G-buffer style visualisations, one thread per pixel, no bounces.
@@ -1334,31 +1385,49 @@ __global__ void __launch_bounds__(LP_BLOCK) k_detmath(int fn, uint32_t n, const 
     out[i] = r;
 }
 
-// tile pack / unpack for the multi-GPU gather: tiles t = rank, rank+world, ... in row-major tile order
-__global__ void __launch_bounds__(LP_BLOCK) k_pack_tiles(const uint2 *tex, uint2 *packed, uint32_t width, uint32_t height,
-                                                         uint32_t tile_px, uint32_t rank, uint32_t world, int unpack)
+// Tile pack / unpack for the multi-GPU gather.  Payload of a rank = its tiles in ascending order (include/lupin_tiles.h),
+// each tile row-major, 8 B per pixel.  One block per tile: the block first sums the pixel counts of the owner's earlier
+// tiles (a few hundred terms at most, strided over the threads), then copies the tile's rows.
+//   mode 0: pack the tiles `rank` owns (blockIdx.x = j-th owned tile) into packed[0 ..)
+//   mode 1: unpack the tiles `rank` owns from packed[0 ..)
+//   mode 2: unpack every tile NOT owned by `rank` (blockIdx.x = tile of the frame) from the all-gathered buffer
+//           packed[owner * capacity_px + ..) -- the whole readback scatter in one launch
+__global__ void __launch_bounds__(LP_BLOCK) k_tiles_copy(uint2 *tex, uint2 *packed, uint32_t width, uint32_t height, uint32_t tile_px,
+                                                        uint32_t rank, uint32_t world, unsigned long long capacity_px, int mode)
 {
-    uint32_t ntx = (width - 1) / tile_px + 1;
-    uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t y = blockIdx.y;
-    if (x >= width || y >= height) return;
-    uint32_t tx = x / tile_px, ty = y / tile_px;
-    uint32_t t = ty * ntx + tx;
-    if (lupin_tile_owner(t, ntx, world) != rank) return;
-    // pixels in this rank's tiles before tile t (tiles are few -- a few thousand at most -- so a loop is fine)
-    unsigned long long before = 0;
-    for (uint32_t j = 0;; j++)
+    const uint32_t ntx = (width - 1) / tile_px + 1;
+    uint32_t t, owner, j;
+    if (mode == 2)
     {
-        const uint32_t q = lupin_owned_tile(j, rank, world, ntx);
-        if (q == t) break;
-        uint32_t qx = (q % ntx) * tile_px, qy = (q / ntx) * tile_px;
-        uint32_t w = min(tile_px, width - qx), h = min(tile_px, height - qy);
-        before += (unsigned long long)w * h;
+        t = blockIdx.x;
+        owner = lupin_tile_owner(t, ntx, world);
+        if (owner == rank) return;
+        j = lupin_owned_index(t, world, ntx);
     }
-    uint32_t ox = tx * tile_px, oy = ty * tile_px;
-    uint32_t w = min(tile_px, width - ox);
-    unsigned long long pi = before + (unsigned long long)(y - oy) * w + (x - ox);
-    if (unpack) const_cast<uint2 *>(tex)[(size_t)y * width + x] = packed[pi];
-    else packed[pi] = tex[(size_t)y * width + x];
+    else { owner = rank; j = blockIdx.x; t = lupin_owned_tile(j, rank, world, ntx); }
+    __shared__ unsigned long long part[LP_BLOCK];
+    unsigned long long mine = 0;
+    for (uint32_t i = threadIdx.x; i < j; i += LP_BLOCK)
+    {
+        const uint32_t q = lupin_owned_tile(i, owner, world, ntx);
+        const uint32_t qx = (q % ntx) * tile_px, qy = (q / ntx) * tile_px;
+        mine += (unsigned long long)min(tile_px, width - qx) * min(tile_px, height - qy);
+    }
+    part[threadIdx.x] = mine;
+    __syncthreads();
+    for (uint32_t s = LP_BLOCK / 2; s > 0; s >>= 1)
+    {
+        if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    const unsigned long long before = part[0] + (mode == 2 ? capacity_px * owner : 0ull);
+    const uint32_t ox = (t % ntx) * tile_px, oy = (t / ntx) * tile_px;
+    const uint32_t w = min(tile_px, width - ox), h = min(tile_px, height - oy);
+    for (uint32_t p = threadIdx.x; p < w * h; p += LP_BLOCK)
+    {
+        const uint32_t x = ox + p % w, y = oy + p / w;
+        if (mode == 0) packed[before + p] = tex[(size_t)y * width + x];
+        else tex[(size_t)y * width + x] = packed[before + p];
+    }
 }
 

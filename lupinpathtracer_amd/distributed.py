@@ -7,9 +7,17 @@ round-robin, rank r owns tiles r, r + world, ... (rows rotated when that would m
 `owned_tiles`) -- interleaved because per-tile cost varies a lot (sky vs geometry).  The one exchange step is the gather of per-tile Rgba16Float payloads at readback: one all-gather of
 equally sized packed buffers (RCCL over xGMI on the GPU box; gloo in the CPU tests).
 
-`TileDeviceOps` is the seam between this host logic and the device: the product implementation calls the HIP
-pack / unpack kernels of the C ABI; tests substitute a numpy implementation to exercise the same code over gloo.
+On the GPU the whole exchange is one C-ABI call, `lupin_hip_gather_framebuffer` (`api.Comm.gather_framebuffer`): pack
+kernel -> ncclAllGather -> unpack kernel on the context's stream, no torch in the process.  `rendezvous` hands rank 0's
+RCCL unique id to the other ranks of a one-process-per-GPU job through a file (the ranks of one node share /tmp).
+
+The functions below restate the tile arithmetic of include/lupin_tiles.h and the payload layout in numpy; `gather_framebuffer`
+runs the same pack -> all-gather -> unpack sequence over any `torch.distributed`-like collective (the CPU tests drive it
+with gloo and `NumpyTileOps`), which pins the layout the HIP kernels must produce.
 """
+import os
+import time
+
 import numpy as np
 
 WORKGROUP_SIZE = 4
@@ -77,39 +85,57 @@ class NumpyTileOps:
         unpack_tiles_numpy(image, packed, tile_size, rank, world)
 
 
-class HipTileOps:
-    """Product implementation: payloads are torch CUDA tensors, pack / unpack run as HIP kernels on the
-    context's stream (lupin_hip_pack_tiles / lupin_hip_unpack_tiles)."""
+def rendezvous_path(env=None):
+    """Where rank 0 publishes the RCCL unique id.  Ranks started by one launcher share their parent process
+    (`torch.distributed.run`'s agent, or bench.py's own spawner), so (parent pid, MASTER_PORT) names the job."""
+    env = os.environ if env is None else env
+    if env.get("LUPIN_RDZV_FILE"):
+        return env["LUPIN_RDZV_FILE"]
+    return os.path.join(env.get("TMPDIR", "/tmp"), f"lupin_rdzv_{os.getppid()}_{env.get('MASTER_PORT', '0')}")
 
-    def __init__(self, torch, ctx, device):
-        self.torch, self.ctx, self.device = torch, ctx, device
 
-    def pack(self, texture, tile_size, rank, world, capacity_pixels):
-        from . import api
-        buf = self.torch.zeros(capacity_pixels, dtype=self.torch.int64, device=self.device)   # 8 B per pixel
-        self.torch.cuda.synchronize(self.device)            # the zero fill runs on torch's stream
-        api.pack_tiles(self.ctx, texture, tile_size, rank, world, buf.data_ptr())
-        self.ctx.sync()                                     # payload complete before the collective reads it
-        return buf
-
-    def unpack(self, texture, payload, tile_size, rank, world):
-        from . import api
-        api.unpack_tiles(self.ctx, texture, tile_size, rank, world, payload.data_ptr())   # enqueued; finish() waits
-
-    def finish(self):
-        self.ctx.sync()   # the payload tensors may be released after this
+def rendezvous(ctx, rank, world, path=None, timeout=300.0):
+    """One-process-per-GPU communicator: rank 0 makes the unique id (ncclGetUniqueId) and writes it atomically to `path`,
+    the others wait for the file; everyone then joins with ncclCommInitRank.  Returns an api.Comm."""
+    from . import api
+    path = path or rendezvous_path()
+    if rank == 0:
+        uid = api.Comm.unique_id()
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)
+    else:
+        deadline = time.monotonic() + timeout
+        while True:
+            try:
+                with open(path, "rb") as f:
+                    uid = f.read()
+                if len(uid) == 128:
+                    break
+            except FileNotFoundError:
+                pass
+            if time.monotonic() > deadline:
+                raise TimeoutError(f"rank {rank}: no RCCL unique id at {path} after {timeout:.0f} s")
+            time.sleep(0.01)
+    comm = api.Comm.init_rank(ctx, uid, rank, world)
+    comm.barrier()   # everyone has read the file
+    if rank == 0:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+    return comm
 
 
 def gather_framebuffer(dist, ops, framebuffer, width, height, tile_size, rank, world):
-    """All-gather the per-rank tile payloads and scatter them into `framebuffer` on every rank.
-    Returns the number of payload bytes this rank contributed."""
+    """Host-logic twin of lupin_hip_gather_framebuffer over a torch.distributed-like collective: all-gather the per-rank tile
+    payloads and scatter them into `framebuffer` on every rank.  Returns the payload bytes this rank contributed."""
     capacity = max(packed_pixels(width, height, tile_size, r, world) for r in range(world))
     mine = ops.pack(framebuffer, tile_size, rank, world, capacity)
     torch = ops.torch
     gathered = torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device)
     dist.all_gather_into_tensor(gathered, mine)
-    if mine.is_cuda:
-        torch.cuda.synchronize(mine.device)
     for r in range(world):
         if r != rank:
             ops.unpack(framebuffer, gathered[r * mine.numel():(r + 1) * mine.numel()], tile_size, r, world)

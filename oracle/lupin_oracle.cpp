@@ -2218,6 +2218,8 @@ struct Inv
         return in_bounds;
     }
 
+    // prev_f32 (optional, W*H*3): the f32-accumulate mode of SURVEY 8d -- the same blend with an unquantised prev_frame
+    const float *prev_f32 = nullptr;
     bool pathtrace_main(uint32_t gx, uint32_t gy, uint32_t dim_x, uint32_t dim_y, const uint16_t *prev_frame, float out_rgb[3])
     {
         init_rng(gy * dim_x + gx);
@@ -2248,6 +2250,7 @@ struct Inv
             float weight = 1.0f / (float)constants.accum_counter;
             const uint16_t *p = prev_frame + ((size_t)gy * dim_x + gx) * 4;
             vec3f prev_color = {half_to_float(p[0]), half_to_float(p[1]), half_to_float(p[2])};
+            if (prev_f32) { const float *q = prev_f32 + ((size_t)gy * dim_x + gx) * 3; prev_color = {q[0], q[1], q[2]}; }
             color = prev_color * (1.0f - weight) + color * weight;
             color = max3(color, v3(0.0f));
         }
@@ -2292,15 +2295,32 @@ struct OracleCounters
 // falsecolor == 1 runs pathtrace_falsecolor_main (pathtracer.wgsl:296-452) with constants->falsecolor_type instead,
 // falsecolor == 2 pathtrace_debug_main (:457-503) with the DEBUG flags / heatmap range of the push constants.
 // Texels outside the dispatch are left untouched.  Returns 0 on success.
+int oracle_pathtrace_f32prev(const LupinSceneDesc *scene, const LupinPushConstants *constants,
+                             uint32_t max_bounces, uint32_t samples_per_pixel,
+                             uint32_t width, uint32_t height, uint32_t groups_x, uint32_t groups_y,
+                             const uint16_t *prev_frame, uint16_t *out_rgba16f, float *out_rgb_f32,
+                             OracleCounters *counters, int num_threads, int store_rounding, int falsecolor, const float *prev_rgb_f32);
 int oracle_pathtrace(const LupinSceneDesc *scene, const LupinPushConstants *constants,
                      uint32_t max_bounces, uint32_t samples_per_pixel,
                      uint32_t width, uint32_t height, uint32_t groups_x, uint32_t groups_y,
                      const uint16_t *prev_frame, uint16_t *out_rgba16f, float *out_rgb_f32,
                      OracleCounters *counters, int num_threads, int store_rounding, int falsecolor)
 {
+    return oracle_pathtrace_f32prev(scene, constants, max_bounces, samples_per_pixel, width, height, groups_x, groups_y, prev_frame, out_rgba16f,
+                                    out_rgb_f32, counters, num_threads, store_rounding, falsecolor, nullptr);
+}
+// the same with an optional unquantised prev_frame (W*H*3 f32): f32-accumulate mode; prev_frame (f16) may then be NULL
+int oracle_pathtrace_f32prev(const LupinSceneDesc *scene, const LupinPushConstants *constants,
+                             uint32_t max_bounces, uint32_t samples_per_pixel,
+                             uint32_t width, uint32_t height, uint32_t groups_x, uint32_t groups_y,
+                             const uint16_t *prev_frame, uint16_t *out_rgba16f, float *out_rgb_f32,
+                             OracleCounters *counters, int num_threads, int store_rounding, int falsecolor, const float *prev_rgb_f32)
+{
     auto to_half = [store_rounding](float f) { return store_rounding == 1 ? float_to_half_rne(f) : float_to_half_rtz(f); };
     if (!scene || !constants || !out_rgba16f) return -1;
-    if (constants->accum_counter != 0 && !prev_frame) return -1;
+    if (constants->accum_counter != 0 && !prev_frame && !prev_rgb_f32) return -1;
+    std::vector<uint16_t> zero_prev;
+    if (!prev_frame && prev_rgb_f32) { zero_prev.assign((size_t)width * height * 4, 0); prev_frame = zero_prev.data(); }
     Counters total;
 #ifdef _OPENMP
     if (num_threads > 0) omp_set_num_threads(num_threads);
@@ -2320,6 +2340,7 @@ int oracle_pathtrace(const LupinSceneDesc *scene, const LupinPushConstants *cons
                 Inv inv;
                 inv.s = scene; inv.constants = *constants;
                 inv.MAX_BOUNCES = max_bounces; inv.SAMPLES_PER_PIXEL = samples_per_pixel;
+                inv.prev_f32 = (falsecolor == 0) ? prev_rgb_f32 : nullptr;
                 float rgb[3];
                 if (falsecolor == 2) inv.pathtrace_debug_main(gx, gy, width, height, prev_frame, rgb);
                 else if (falsecolor) inv.pathtrace_falsecolor_main(gx, gy, width, height, prev_frame, rgb);

@@ -40,6 +40,8 @@ def lib():
         h.oracle_pathtrace.argtypes = [C.POINTER(_abi.SceneDesc), C.POINTER(_abi.PushConstants), C.c_uint32, C.c_uint32,
                                        C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.POINTER(OracleCounters), C.c_int, C.c_int, C.c_int]
+        h.oracle_pathtrace_f32prev.restype = C.c_int
+        h.oracle_pathtrace_f32prev.argtypes = list(h.oracle_pathtrace.argtypes) + [C.c_void_p]
         h.oracle_trace_rays.restype = C.c_int
         h.oracle_trace_rays.argtypes = [C.POINTER(_abi.SceneDesc), C.c_uint32, C.c_void_p, C.c_void_p, C.c_float, C.c_uint32,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -102,8 +104,9 @@ def dispatch_extent(width, height, tile_params=None):
 
 def pathtrace(scene, width, height, camera_params, camera_transform, max_bounces=8, samples_per_pixel=5, pathtrace_type=0,
               accum_counter=0, prev_frame=None, advanced=None, tile_params=None, out=None, num_threads=0, want_f32=False,
-              store_rounding=0, falsecolor_type=None, debug_desc=None):
-    """One pathtrace_scene call on the CPU.  Returns (rgba16f (H,W,4) float16, counters dict[, rgb f32])."""
+              store_rounding=0, falsecolor_type=None, debug_desc=None, prev_frame_f32=None):
+    """One pathtrace_scene call on the CPU.  Returns (rgba16f (H,W,4) float16, counters dict[, rgb f32]).
+    prev_frame_f32 ((H,W,3) float32): f32-accumulate mode, the blend reads this instead of the f16 prev_frame."""
     (ox, oy), gx, gy = dispatch_extent(width, height, tile_params)
     pc = push_constants(scene, camera_params, camera_transform, pathtrace_type, accum_counter, advanced, (ox, oy))
     if falsecolor_type is not None:
@@ -118,22 +121,26 @@ def pathtrace(scene, width, height, camera_params, camera_transform, max_bounces
         pc.heatmap_max = float(debug_desc.heatmap_max)
     if out is None:
         out = np.zeros((height, width, 4), np.float16)
-    f32 = np.zeros((height, width, 3), np.float32) if want_f32 else None
+    f32 = want_f32 if isinstance(want_f32, np.ndarray) else (np.zeros((height, width, 3), np.float32) if want_f32 else None)
     prev = None
     if prev_frame is not None:
         prev = np.ascontiguousarray(prev_frame, np.float16)
         assert prev.shape == (height, width, 4)
     cnt = OracleCounters()
-    rc = lib().oracle_pathtrace(C.byref(scene.desc), C.byref(pc), max_bounces, samples_per_pixel, width, height, gx, gy,
-                                _abi.ptr(prev), _abi.ptr(out), _abi.ptr(f32), C.byref(cnt), num_threads, store_rounding,
-                                2 if debug_desc is not None else (0 if falsecolor_type is None else 1))
+    p32 = None
+    if prev_frame_f32 is not None:
+        p32 = np.ascontiguousarray(prev_frame_f32, np.float32)
+        assert p32.shape == (height, width, 3)
+    rc = lib().oracle_pathtrace_f32prev(C.byref(scene.desc), C.byref(pc), max_bounces, samples_per_pixel, width, height, gx, gy,
+                                        _abi.ptr(prev), _abi.ptr(out), _abi.ptr(f32), C.byref(cnt), num_threads, store_rounding,
+                                        2 if debug_desc is not None else (0 if falsecolor_type is None else 1), _abi.ptr(p32))
     if rc != 0:
         raise RuntimeError("oracle_pathtrace failed")
     counters = {}
     for k, t in OracleCounters._fields_:
         v = getattr(cnt, k)
         counters[k] = int(v) if t is C.c_uint64 else [int(x) for x in v]   # 3-vectors: [extend, light-pdf, shadow]
-    return (out, counters, f32) if want_f32 else (out, counters)
+    return (out, counters, f32) if f32 is not None else (out, counters)
 
 
 def trace_rays(scene, ori, dir_, ray_epsilon=0.001, flags=0):

@@ -1,18 +1,23 @@
-"""Worker of test_bench_cli.py::test_gather_framebuffer_with_device_payloads: world 3 on one GPU, the other ranks'
-payloads come from a stand-in collective, the gathered frame must equal the single-dispatch frame."""
+"""Worker of test_bench_cli.py::test_gather_through_the_c_abi (its own process: it loads librccl).
+
+1. world 3 on one GPU without a collective: every "rank" renders its tiles, the payloads are laid out as an all-gather
+   would leave them, lupin_hip_unpack_gathered_tiles scatters them -- every rank's frame must equal the single dispatch.
+2. lupin_hip_gather_framebuffer through a real RCCL communicator of world size 1 (rendezvous file, ncclCommInitRank,
+   ncclAllGather on the context's stream), with HIP-graph replay on when LUPIN_GRAPH=1 is set by the caller.
+3. exactly one HIP runtime is mapped in the process, the one the library was built against."""
 import os
 import sys
 
-import torch   # first: torch ships its own HIP runtime
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-torch.cuda.set_device(0)
 
 from lupinpathtracer_amd import api, distributed, loader   # noqa: E402
 from tests import util   # noqa: E402
 
+assert "torch" not in sys.modules
 ctx = api.Context(0)
+info = api.runtime_info()
+assert info["num_hip_runtimes_mapped"] == 1 and info["build_hip_version"] // 100000 == info["runtime_hip_version"] // 100000, info
 scene, cams = loader.build_scene_cornell_box(ctx)
 cam = cams[0]
 W, H, ts, world = 200, 136, 4, 3          # 13 x 9 tiles of 16 px, partial tiles on both edges
@@ -20,24 +25,37 @@ res = api.build_pathtrace_resources(ctx, api.BakedPathtraceParams(max_bounces=5,
 desc = api.PathtraceDesc(camera_params=cam.params, camera_transform=cam.transform)
 full = api.Texture(ctx, W, H)
 api.pathtrace_scene(ctx, res, scene, full, 0, desc)
-ops = distributed.HipTileOps(torch, ctx, torch.device("cuda", 0))
+want = full.download()
+
 capacity = max(distributed.packed_pixels(W, H, ts, r, world) for r in range(world))
-shards, payloads = [], []
+gathered = api.Texture(ctx, capacity * world, 1)      # any device buffer of world * capacity * 8 bytes
+shards = []
 for r in range(world):
     t = api.Texture(ctx, W, H)
     api.pathtrace_scene_tiles(ctx, res, scene, t, 0, desc, ts, r, world)
     shards.append(t)
-    payloads.append(ops.pack(t, ts, r, world, capacity))
+    assert api.pack_tiles(ctx, t, ts, r, world, gathered.device_ptr() + r * capacity * 8) == distributed.packed_pixels(W, H, ts, r, world)
+for r in range(world):
+    api.unpack_gathered_tiles(ctx, shards[r], ts, r, world, gathered.device_ptr(), capacity)
+    assert util.f16_words_differ(shards[r].download(), want) == 0, r
+print("SCATTER OK")
 
-
-class StandInCollective:
-    def all_gather_into_tensor(self, out, mine):
-        for r in range(world):
-            out[r * mine.numel():(r + 1) * mine.numel()].copy_(payloads[r])
-
-
-want = full.download()
-for rank in range(world):
-    distributed.gather_framebuffer(StandInCollective(), ops, shards[rank], W, H, ts, rank, world)
-    assert util.f16_words_differ(shards[rank].download(), want) == 0, rank
+comm = distributed.rendezvous(ctx, 0, 1, path=os.path.join(os.environ.get("TMPDIR", "/tmp"), f"lupin_rdzv_test_{os.getpid()}"))
+assert (comm.rank, comm.world) == (0, 1)
+out = api.DoubleBufferedTexture(ctx, W, H)
+for k in range(4):   # frames, a gather in the middle, more frames: the sequence that faulted under graph replay in round 1
+    api.pathtrace_scene_tiles(ctx, res, scene, out.front(), 0,
+                              api.PathtraceDesc(accum_params=api.AccumulationParams(out.back(), k), camera_params=cam.params, camera_transform=cam.transform),
+                              ts, 0, 1)
+    if k == 1:
+        comm.gather_framebuffer(out.front(), ts)
+    out.flip()
+out.flip()
+comm.gather_framebuffer(out.front(), ts)
+got = out.front().download()
+ref = util.gpu_accumulate(ctx, scene, cam, W, H, frames=4, spp=2, max_bounces=5)
+assert util.f16_words_differ(got, ref) == 0
+assert float(comm.allreduce([3.0, 4.0], "sum")[1]) == 4.0 and float(comm.allreduce([5.0], "max")[0]) == 5.0
+comm.barrier()
+comm.close()
 print("GATHER OK")

@@ -1,5 +1,6 @@
-"""bench.py as the driver runs it, including the N > 1 code path (tile-set dispatch + RCCL all-gather at readback)
-forced onto one GPU: the JSON contract, parity fields, and that the distributed path survives its own warm-up gather."""
+"""bench.py as the driver runs it: the JSON contract, roofline / parity fields on a small workload, the N > 1 code path
+(tile-set dispatch + RCCL gather behind the C ABI) forced onto one GPU -- also with HIP-graph replay on, the
+configuration that faulted in round 1 -- and the launcher-less `--gpus N` form."""
 import json
 import os
 import subprocess
@@ -8,39 +9,69 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-pytestmark = pytest.mark.gpu
+SMALL = ["--scene", "cornellbox", "--width", "256", "--height", "256", "--bounces", "8"]
 
 
-def run_bench(extra_env, *args):
+def run_bench(extra_env, *args, check=True):
     env = dict(os.environ)
     env.update(extra_env)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, env=env, timeout=600)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, env=env, timeout=900)
+    if not check:
+        return p
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     return json.loads(lines[0])
 
 
+@pytest.mark.gpu
 def test_bench_line_contract(built):
-    d = run_bench({}, "--steps", "4", "--warmup", "2", "--size", "256")
+    d = run_bench({}, "--steps", "4", "--warmup", "2", *SMALL)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline", "parity"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["value"] > 0 and d["higher_is_better"] is True
-    assert "workload" in d["config"] and d["vs_baseline"] is None and d["scaling"] == "weak"
+    assert "workload" in d["config"] and d["vs_baseline"] is None and d["scaling"] == "strong"
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
     assert d["parity"]["differing_f16_words"] == 0 and d["parity"]["rmse_vs_cpu_restatement"] == 0.0
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["achieved"] > 0 and r["bytes_per_unit"] > 56 and r["peak_measured"] > 1000
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert d["hip_runtime"]["num_hip_runtimes_mapped"] == 1
 
 
-def test_distributed_bench_path_on_one_gpu(built):
-    """world_size 1 through torch.distributed + RCCL: warm-up gather, timed steps, final gather."""
-    env = {"LUPIN_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"}
-    d = run_bench(env, "--steps", "6", "--warmup", "4", "--no-cpu-baseline")
-    assert d["n_gpus"] == 1 and d["value"] > 0 and d["path_bounces"] > 0
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph", ["0", "1"])
+def test_distributed_bench_path_on_one_gpu(built, graph):
+    """world_size 1 through the rendezvous file + RCCL: warm-up gather, timed steps, final gather; graph = "1" is the
+    configuration that died with a memory fault in round 1 (then on a PyTorch wheel's HIP 7.0 runtime)."""
+    env = {"LUPIN_BENCH_FORCE_DIST": "1", "LUPIN_GRAPH": graph, "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533", "RANK": "0",
+           "WORLD_SIZE": "1", "LOCAL_RANK": "0"}
+    d = run_bench(env, "--steps", "6", "--warmup", "4", "--no-cpu-baseline", *SMALL)
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["path_bounces"] > 0 and "tile-sharded" in d["config"]["sharding"]
 
 
-def test_gather_framebuffer_with_device_payloads(built):
-    """distributed.gather_framebuffer + HipTileOps (torch CUDA payloads, pack / unpack kernels) for world 3 on one GPU
-    (tests/_gather_worker.py; its own process because torch brings its own HIP runtime, which has to load first)."""
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_gather_worker.py")], capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0 and "GATHER OK" in p.stdout, p.stdout[-1500:] + p.stderr[-1500:]
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph", ["0", "1"])
+def test_gather_through_the_c_abi(built, graph):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_gather_worker.py")], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, LUPIN_GRAPH=graph))
+    assert p.returncode == 0 and "SCATTER OK" in p.stdout and "GATHER OK" in p.stdout, p.stdout[-1500:] + p.stderr[-1500:]
+
+
+def test_gpus_n_without_launcher_spawns_ranks_or_fails(built):
+    """`python bench.py --gpus 2` with no launcher must not print a 1-GPU line: it starts two rank processes itself; where
+    they cannot run (no second GPU / no GPU at all) the command fails."""
+    from lupinpathtracer_amd import api
+    if api.device_count() >= 2:
+        pytest.skip("two GPUs present: the spawned job would run")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", *SMALL],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_world_size_mismatch_is_an_error(built):
+    p = run_bench({"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"}, "--gpus", "1", *SMALL, check=False)
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
