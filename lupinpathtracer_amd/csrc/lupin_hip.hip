@@ -1295,7 +1295,7 @@ int lupin_hip_measure_copy_bandwidth(LupinContext *ctx, uint64_t bytes, uint32_t
     if (e != hipSuccess) { if (a) hipFree(a); return fail(LUPIN_ERR_OUT_OF_MEMORY, hipGetErrorString(e)); }
     hipEvent_t e0 = get_event(ctx), e1 = get_event(ctx);
     HIP_TRY(hipMemsetAsync(a, 0x3C, n * 16, ctx->stream));
-    const uint32_t blocks = ctx->num_cus * 8;
+    const uint32_t blocks = ctx->num_cus * 16;
     hipLaunchKernelGGL(k_copy_bw, dim3(blocks), dim3(LP_BLOCK), 0, ctx->stream, (const float4 *)a, b, n);   // warm-up: pages touched
     HIP_TRY(hipEventRecord(e0, ctx->stream));
     for (uint32_t r = 0; r < reps; r++)

@@ -1090,7 +1090,13 @@ __global__ void __launch_bounds__(LP_BLOCK) k_resolve(FrameParams fp, PathBuffer
 __global__ void __launch_bounds__(LP_BLOCK) k_copy_bw(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n)
 {
     const size_t stride = (size_t)gridDim.x * LP_BLOCK;
-    for (size_t i = (size_t)blockIdx.x * LP_BLOCK + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+    size_t i = (size_t)blockIdx.x * LP_BLOCK + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride)   // four independent 16-byte loads in flight per lane
+    {
+        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
 }
 
 // pathtrace_falsecolor_main (pathtracer.wgsl:296-452): G-buffer style visualisations, one thread per pixel, no bounces.

@@ -127,6 +127,8 @@ def pathtrace(scene, width, height, camera_params, camera_transform, max_bounces
         prev = np.ascontiguousarray(prev_frame, np.float16)
         assert prev.shape == (height, width, 4)
     cnt = OracleCounters()
+    if num_threads <= 0:
+        num_threads = globals()["num_threads"]()   # never oversubscribe the cgroup's CPU share: 256 spinning threads on 16 CPUs crawl
     p32 = None
     if prev_frame_f32 is not None:
         p32 = np.ascontiguousarray(prev_frame_f32, np.float32)
@@ -177,8 +179,22 @@ def bsdf_probe(mat_type, color, roughness, metallic, ior, normal, outgoing, rnl,
     return inc, ev, float(pdf.value)
 
 
+def effective_cpus():
+    """CPUs this process may actually use: the cgroup's quota (a GPU box shows all 256 hardware threads but grants 16) and
+    the affinity mask, whichever is smaller."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def num_threads():
-    return int(lib().oracle_num_threads())
+    """OpenMP threads the oracle runs with when `num_threads=0` is passed to pathtrace."""
+    return min(int(lib().oracle_num_threads()), effective_cpus())
 
 
 def tonemap(src_rgba16f, dst_width, dst_height, desc=None, dst=None):

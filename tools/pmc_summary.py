@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Folds rocprofv3 --pmc counter_collection.csv files (one directory per pass) into profiles/<name>.json and
-refreshes profiles/r01_pmc_traffic.json (HBM bytes per path-bounce per kernel, used by bench.py's roofline.traffic).
+refreshes profiles/pmc_traffic_last.json (HBM bytes per path-bounce per kernel, used by bench.py's roofline.traffic).
 
     python tools/pmc_summary.py <units> <out.json> <pass_dir> [<pass_dir> ...]
 """
@@ -40,7 +40,7 @@ def main():
     json.dump({"path_bounces": units, "kernels": kernels, "derived": derived}, open(out_path, "w"), indent=1)
     if traffic:
         json.dump({"source": os.path.basename(out_path), "hbm_bytes_per_unit": traffic},
-                  open(os.path.join(os.path.dirname(out_path), "r01_pmc_traffic.json"), "w"), indent=1)
+                  open(os.path.join(os.path.dirname(out_path), "pmc_traffic_last.json"), "w"), indent=1)
     print(json.dumps(derived, indent=1))
 
 
