@@ -176,8 +176,9 @@ class Context:
     def stats(self):
         s = _abi.StatsC()
         check(lib().lupin_hip_stats_get(self.handle, C.byref(s)))
-        return {k: (getattr(s, k) if not hasattr(getattr(s, k), "__len__") else [int(v) for v in getattr(s, k)])
-                for k, _ in _abi.StatsC._fields_}
+        def conv(v):
+            return [conv(x) for x in v] if hasattr(v, "__len__") else v
+        return {k: conv(getattr(s, k)) for k, _ in _abi.StatsC._fields_}
 
     def set_accumulation_mode(self, mode):
         """0 = f16 running average (reference-faithful, default), 1 = f32 accumulator per texture (pathtracer.wgsl:275-289)."""

@@ -29,7 +29,7 @@ static int fail(int code, const std::string &msg) { g_last_error = msg; return c
 #define HIP_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return fail(LUPIN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } while (0)
 
 #define LP_MAX_LANES 4
-#define LP_WORK_WORDS 12   // 3 tracing modes (closest hit | shadow rays | light-pdf marching) x {nodes, triangles, instances}, padded
+#define LP_WORK_WORDS 24   // 3 tracing modes (closest hit | shadow rays | light-pdf marching) x {nodes, triangles, instances, node fetches}
 // "Lanes" (stream + path buffers + counters) let consecutive pathtrace_scene calls overlap: the wavefront of
 // frame k+1 starts while the thin tail of frame k is still draining.  Frames only meet at k_resolve (frame k+1 blends
 // with frame k's output), which waits on the previous call's completion event.
@@ -40,6 +40,8 @@ struct Lane
     uint64_t capacity = 0;          // slots the path buffers hold
     uint32_t counts_capacity = 0;
     unsigned long long *stat_counters = nullptr;   // per shard: [2s] path bounces, [2s+1] paths
+    uint32_t *stack_overflow = nullptr;            // deep tail of the persistent tracer's traversal stacks (SplitStack)
+    uint64_t overflow_capacity = 0;                // words
     unsigned long long *work_counters = nullptr;   // [3 * mode + {nodes, triangles, instances}] of the COUNT kernels (stats mode 2)
     hipEvent_t done = nullptr;      // recorded after the last kernel of the lane's latest call
     bool used = false;
@@ -49,7 +51,7 @@ struct Lane
     struct GraphKey
     {
         uint64_t scene_id = 0, pb_generation = 0;
-        uint32_t n = 0, blocks = 0, type = 0, iterations = 0, stack_words = 0, lds = 0, pblocks = 0, refill_min = 0, node_steps = 0;
+        uint32_t n = 0, blocks = 0, type = 0, iterations = 0, full_words = 0, light_words = 0, persist_words = 0, blob_bytes = 0, pblocks = 0, refill_min = 0, node_steps = 0;
         int persistent = 0, persistent_shadow = 0, lds_geometry = 0;
         bool operator==(const GraphKey &o) const { return memcmp(this, &o, sizeof(GraphKey)) == 0; }
     } graph_key, seen_key;           // key of graph_exec | key of the lane's previous call
@@ -80,6 +82,7 @@ struct LupinContext
     bool use_graph = false;                 // LUPIN_GRAPH=1: replay the lane-private wavefront as a HIP graph (opt-in)
     bool persistent_shadow = true;          // LUPIN_SHADOW=simple: MIS / Direct shadow rays stay in k_shadow even on large scenes
     uint32_t node_steps = 4;               // LUPIN_NODE_STEPS: node visits per scheduling round of k_extend_persistent
+    uint32_t persist_lds_words = 32;       // LUPIN_STACK_LDS_WORDS (32 | 64 | 128): traversal-stack ring of the persistent tracer, words per lane in LDS
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_extend, ev_shade, ev_total;
     std::vector<hipEvent_t> ev_pool;
     uint64_t extend_launches = 0;
@@ -103,13 +106,91 @@ struct LupinScene
     LupinContext *ctx;
     SceneDev dev{};
     std::vector<void *> allocations;
-    uint32_t stack_entries = 1;
+    uint32_t stack_entries = 1;                     // worst-case traversal-stack words of a closest-hit query (TLAS + deepest BLAS)
+    uint32_t light_stack_entries = 1;               // ... of light-pdf marching (the BLAS of one emissive instance)
     uint32_t persistent_blocks[4] = {0, 0, 0, 0};   // grid of k_extend_persistent per integrator (lazy)
     uint64_t id = 0;                                // unique per created scene (graph cache key)
     bool all_opaque = false;                        // no instance can have opacity != 1: k_extend<.., OPAQUE> drops the alpha test
     bool simple_matte = false;                      // only untextured matte materials, no vertex colours, no environments: k_shade<.., SIMPLE>
     bool has_sw_bvh = false;
     bool envs_empty = true, lights_empty = true, instances_empty = true;
+};
+
+// ---- binary hierarchy -> QNodes (lupin_device.hpp) ----
+// `T` gives access to one binary tree: is_leaf(n), leaf_ref(n), leaf_words(n) (stack words a traversal below that leaf can
+// need: 0 for triangles, the mesh's figure for an instance), child(n, side), lo(n) / hi(n).
+// Returns the reference of node n and the worst-case number of stack words a traversal of its subtree can hold at once
+// (relative to the height at entry): at a node the far side is parked (4 words for a PAIR, 1 for a SINGLE) while the near
+// side is descended; a PAIR side parks one more word, the far grandchild.
+struct QOut { uint32_t ref, words; };
+template <typename T>
+static QOut build_qnodes(const T &t, uint32_t n, std::vector<QNode> &out, uint32_t base, bool use_pairs)
+{
+    if (t.is_leaf(n)) return {t.leaf_ref(n), t.leaf_words(n)};
+    const uint32_t idx = (uint32_t)out.size();
+    out.emplace_back();
+    float box[4][6];
+    uint32_t refs[4] = {REF_NONE, REF_NONE, REF_NONE, REF_NONE};   // slot 1 / 3 left at REF_NONE marks the side SINGLE
+    memset(box, 0, sizeof(box));
+    uint32_t cost[2], sub[2];
+    for (uint32_t side = 0; side < 2; side++)
+    {
+        const uint32_t c = t.child(n, side);
+        bool pair = use_pairs && !t.is_leaf(c);
+        uint32_t g0 = 0, g1 = 0;
+        if (pair)
+        {
+            g0 = t.child(c, 0); g1 = t.child(c, 1);
+            for (int k = 0; k < 3 && pair; k++)   // the child's box must be the exact union of its children's
+                pair = t.lo(c)[k] == std::min(t.lo(g0)[k], t.lo(g1)[k]) && t.hi(c)[k] == std::max(t.hi(g0)[k], t.hi(g1)[k]);
+        }
+        if (pair)
+        {
+            for (int k = 0; k < 3; k++)
+            {
+                box[2 * side][k] = t.lo(g0)[k]; box[2 * side][3 + k] = t.hi(g0)[k];
+                box[2 * side + 1][k] = t.lo(g1)[k]; box[2 * side + 1][3 + k] = t.hi(g1)[k];
+            }
+            const QOut a = build_qnodes(t, g0, out, base, use_pairs), b = build_qnodes(t, g1, out, base, use_pairs);
+            refs[2 * side] = a.ref; refs[2 * side + 1] = b.ref;
+            cost[side] = 4; sub[side] = 1 + std::max(a.words, b.words);
+        }
+        else
+        {
+            for (int k = 0; k < 3; k++) { box[2 * side][k] = t.lo(c)[k]; box[2 * side][3 + k] = t.hi(c)[k]; }
+            const QOut a = build_qnodes(t, c, out, base, use_pairs);
+            refs[2 * side] = a.ref;
+            cost[side] = 1; sub[side] = a.words;
+        }
+    }
+    QNode q;
+    const float *f = &box[0][0];
+    for (int k = 0; k < 6; k++) q.w[k] = make_float4(f[4 * k + 0], f[4 * k + 1], f[4 * k + 2], f[4 * k + 3]);
+    q.w[6] = make_float4(host_u2f(refs[0]), host_u2f(refs[1]), host_u2f(refs[2]), host_u2f(refs[3]));
+    q.w[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    out[idx] = q;
+    return {idx - base, std::max(cost[1] + sub[0], cost[0] + sub[1])};
+}
+
+struct BlasTree
+{
+    const LupinBvhNode *nodes; uint32_t tri_offset;
+    bool is_leaf(uint32_t n) const { return nodes[n].tri_count > 0; }
+    uint32_t leaf_ref(uint32_t n) const { return REF_LEAF | (tri_offset + nodes[n].tri_begin_or_first_child); }
+    uint32_t leaf_words(uint32_t) const { return 0; }
+    uint32_t child(uint32_t n, uint32_t side) const { return nodes[n].tri_begin_or_first_child + side; }
+    const float *lo(uint32_t n) const { return nodes[n].aabb_min; }
+    const float *hi(uint32_t n) const { return nodes[n].aabb_max; }
+};
+struct TlasTree
+{
+    const LupinTlasNode *nodes; const LupinInstance *instances; const uint32_t *mesh_words;
+    bool is_leaf(uint32_t n) const { return nodes[n].left == 0; }
+    uint32_t leaf_ref(uint32_t n) const { return REF_LEAF | nodes[n].instance_idx; }
+    uint32_t leaf_words(uint32_t n) const { return mesh_words[instances[nodes[n].instance_idx].mesh_idx]; }
+    uint32_t child(uint32_t n, uint32_t side) const { return side == 0 ? nodes[n].left : nodes[n].right; }
+    const float *lo(uint32_t n) const { return nodes[n].aabb_min; }
+    const float *hi(uint32_t n) const { return nodes[n].aabb_max; }
 };
 
 template <typename T>
@@ -193,6 +274,15 @@ static uint32_t blas_depth(const LupinBvhNode *nodes, uint32_t count)
     return best;
 }
 
+// Dynamic LDS of the stage kernels: [traversal stack words x LP_BLOCK][geometry blob, if staged].  Each kernel sizes the
+// stack for the traversals it runs: closest-hit kernels the scene's worst case, k_shade the light-pdf marching of one
+// BLAS, the persistent tracer a fixed number of words (the deep tail goes to global memory).
+struct StackPlan
+{
+    uint32_t full_words = 1, light_words = 1, persist_words = 1, blob_bytes = 0;
+    size_t lds(uint32_t words) const { return (size_t)words * LP_BLOCK * sizeof(uint32_t) + blob_bytes; }
+};
+
 // grid of the persistent tracer: as many blocks as the device keeps resident with this scene's traversal-stack size
 // (whole waves per shard); queried once per scene and integrator, outside any stream capture
 template <int TYPE, bool LDSGEO>
@@ -226,8 +316,10 @@ static uint32_t persistent_grid(LupinContext *ctx, const LupinScene *scene, uint
 }
 
 template <int TYPE, bool LDSGEO>
-static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *scene, uint32_t blocks, uint32_t pblocks, size_t lds, uint32_t stack_words, uint32_t iter)
+static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *scene, uint32_t blocks, uint32_t pblocks, const StackPlan &plan, uint32_t iter)
 {
+    const size_t lds = plan.lds(plan.full_words), lds_p = plan.lds(plan.persist_words), lds_s = plan.lds(plan.light_words);
+    const uint32_t stack_words = plan.full_words * LP_BLOCK, stack_words_p = plan.persist_words * LP_BLOCK, stack_words_s = plan.light_words * LP_BLOCK;
     hipStream_t st = ln->stream;
     const FrameParams *fp = ln->d_fp;
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
@@ -237,11 +329,11 @@ static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *sc
     if (persistent)
     {
         if (ctx->counting)
-            hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, 0, true>), dim3(pblocks), dim3(LP_BLOCK), lds, st,
-                               scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words, ctx->node_steps, work);
+            hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, 0, true>), dim3(pblocks), dim3(LP_BLOCK), lds_p, st,
+                               scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words_p, ctx->node_steps, work, ln->stack_overflow);
         else
-            hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, 0, false>), dim3(pblocks), dim3(LP_BLOCK), lds, st,
-                               scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words, ctx->node_steps, work);
+            hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, 0, false>), dim3(pblocks), dim3(LP_BLOCK), lds_p, st,
+                               scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words_p, ctx->node_steps, work, ln->stack_overflow);
     }
     else
     {
@@ -258,21 +350,21 @@ static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *sc
     }
     if (ctx->timing) hipEventRecord(e1, st);
     if (scene->simple_matte && ctx->specialize_simple)
-        hipLaunchKernelGGL((k_shade<TYPE, LDSGEO, true>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
+        hipLaunchKernelGGL((k_shade<TYPE, LDSGEO, true>), dim3(blocks), dim3(LP_BLOCK), lds_s, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words_s);
     else
-        hipLaunchKernelGGL((k_shade<TYPE, LDSGEO, false>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
+        hipLaunchKernelGGL((k_shade<TYPE, LDSGEO, false>), dim3(blocks), dim3(LP_BLOCK), lds_s, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words_s);
     if constexpr (TYPE == LUPIN_PATHTRACE_MIS || TYPE == LUPIN_PATHTRACE_DIRECT)   // shadow rays + path finish (booked with "shade" in the timing)
     {
         if (persistent && ctx->persistent_shadow)
         {
             // large scenes: the shadow rays go through the phase-scheduled persistent tracer as well, then a light finish pass
             if (ctx->counting)
-                hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, 1, true>), dim3(pblocks), dim3(LP_BLOCK), lds, st,
-                                   scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words, ctx->node_steps, work);
+                hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, 1, true>), dim3(pblocks), dim3(LP_BLOCK), lds_p, st,
+                                   scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words_p, ctx->node_steps, work, ln->stack_overflow);
             else
-                hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, 1, false>), dim3(pblocks), dim3(LP_BLOCK), lds, st,
-                                   scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words, ctx->node_steps, work);
-            hipLaunchKernelGGL((k_shadow<TYPE, LDSGEO, true>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, stack_words);
+                hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, 1, false>), dim3(pblocks), dim3(LP_BLOCK), lds_p, st,
+                                   scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words_p, ctx->node_steps, work, ln->stack_overflow);
+            hipLaunchKernelGGL((k_shadow<TYPE, LDSGEO, true>), dim3(blocks), dim3(LP_BLOCK), lds_s, st, scene->dev, fp, ln->pb, iter, stack_words_s);   // no traversal: the rays were traced above
         }
         else
             hipLaunchKernelGGL((k_shadow<TYPE, LDSGEO, false>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, stack_words);
@@ -287,15 +379,15 @@ static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *sc
 }
 
 template <int TYPE>
-static void launch_iteration(LupinContext *ctx, Lane *ln, const LupinScene *scene, bool lds_geo, uint32_t blocks, uint32_t pblocks, size_t lds, uint32_t stack_words, uint32_t iter)
+static void launch_iteration(LupinContext *ctx, Lane *ln, const LupinScene *scene, bool lds_geo, uint32_t blocks, uint32_t pblocks, const StackPlan &plan, uint32_t iter)
 {
-    if (lds_geo) launch_iteration_t<TYPE, true>(ctx, ln, scene, blocks, pblocks, lds, stack_words, iter);
-    else launch_iteration_t<TYPE, false>(ctx, ln, scene, blocks, pblocks, lds, stack_words, iter);
+    if (lds_geo) launch_iteration_t<TYPE, true>(ctx, ln, scene, blocks, pblocks, plan, iter);
+    else launch_iteration_t<TYPE, false>(ctx, ln, scene, blocks, pblocks, plan, iter);
 }
 
 // the lane-private part of one call: clear the queue counters, first rays, every iteration of the wavefront
 static hipError_t enqueue_wavefront(LupinContext *ctx, Lane *ln, const LupinScene *scene, uint32_t pathtrace_type, bool lds_geo, uint32_t n,
-                                    uint32_t blocks, uint32_t pblocks, size_t lds, uint32_t stack_words, uint32_t iterations)
+                                    uint32_t blocks, uint32_t pblocks, const StackPlan &plan, uint32_t iterations)
 {
     hipStream_t st = ln->stream;
     hipError_t e = hipMemsetAsync(ln->pb.counts, 0, (size_t)ln->counts_capacity * LP_SHARDS * sizeof(uint32_t), st);
@@ -305,10 +397,10 @@ static hipError_t enqueue_wavefront(LupinContext *ctx, Lane *ln, const LupinScen
     {
         switch (pathtrace_type)
         {
-        case LUPIN_PATHTRACE_STANDARD: launch_iteration<LUPIN_PATHTRACE_STANDARD>(ctx, ln, scene, lds_geo, blocks, pblocks, lds, stack_words, it); break;
-        case LUPIN_PATHTRACE_MIS: launch_iteration<LUPIN_PATHTRACE_MIS>(ctx, ln, scene, lds_geo, blocks, pblocks, lds, stack_words, it); break;
-        case LUPIN_PATHTRACE_NAIVE: launch_iteration<LUPIN_PATHTRACE_NAIVE>(ctx, ln, scene, lds_geo, blocks, pblocks, lds, stack_words, it); break;
-        default: launch_iteration<LUPIN_PATHTRACE_DIRECT>(ctx, ln, scene, lds_geo, blocks, pblocks, lds, stack_words, it); break;
+        case LUPIN_PATHTRACE_STANDARD: launch_iteration<LUPIN_PATHTRACE_STANDARD>(ctx, ln, scene, lds_geo, blocks, pblocks, plan, it); break;
+        case LUPIN_PATHTRACE_MIS: launch_iteration<LUPIN_PATHTRACE_MIS>(ctx, ln, scene, lds_geo, blocks, pblocks, plan, it); break;
+        case LUPIN_PATHTRACE_NAIVE: launch_iteration<LUPIN_PATHTRACE_NAIVE>(ctx, ln, scene, lds_geo, blocks, pblocks, plan, it); break;
+        default: launch_iteration<LUPIN_PATHTRACE_DIRECT>(ctx, ln, scene, lds_geo, blocks, pblocks, plan, it); break;
         }
     }
     return hipSuccess;
@@ -421,6 +513,8 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
     if (shd && strcmp(shd, "simple") == 0) ctx->persistent_shadow = false;
     const char *ns = getenv("LUPIN_NODE_STEPS");
     if (ns) ctx->node_steps = (uint32_t)std::min(16, std::max(1, atoi(ns)));
+    const char *slw = getenv("LUPIN_STACK_LDS_WORDS");
+    if (slw) { const int v = atoi(slw); ctx->persist_lds_words = v >= 128 ? 128u : (v >= 64 ? 64u : 32u); }
     const char *rm = getenv("LUPIN_REFILL_MIN");
     if (rm) ctx->refill_min = (uint32_t)std::min(64, std::max(1, atoi(rm)));
     *out_ctx = ctx;
@@ -437,7 +531,7 @@ void lupin_hip_destroy_context(LupinContext *ctx)
         PathBuffers &pb = ctx->lanes[k].pb;
         void *ptrs[] = {pb.ori_rng, pb.dir_meta, pb.weight, pb.radiance, pb.color, pb.hit, pb.hit_tri, pb.vol0, pb.vol1,
                         pb.next_hit, pb.next_tri, pb.queue[0], pb.queue[1], pb.counts, ctx->lanes[k].stat_counters,
-                        pb.sh_org, pb.sh_d0, pb.sh_f0, pb.sh_d1, pb.sh_f1, pb.sh_hit1, ctx->lanes[k].work_counters};
+                        pb.sh_org, pb.sh_d0, pb.sh_f0, pb.sh_d1, pb.sh_f1, pb.sh_hit1, ctx->lanes[k].work_counters, ctx->lanes[k].stack_overflow};
         for (void *p : ptrs) if (p) hipFree(p);
         if (ctx->lanes[k].done) hipEventDestroy(ctx->lanes[k].done);
         if (ctx->lanes[k].graph_exec) hipGraphExecDestroy(ctx->lanes[k].graph_exec);
@@ -561,13 +655,15 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
         for (uint32_t v = 0; v < s.verts_color_array[b].num_verts; v++) { const float *p = s.verts_color_array[b].data + (size_t)v * 4; colors.push_back(make_float4(p[0], p[1], p[2], p[3])); }
     }
 
-    // ---- meshes: triangles in leaf order, BLAS as 64-byte child-pair nodes ----
+    // ---- meshes: triangles in leaf order, BLAS as 128-byte two-level nodes ----
     std::vector<TriVerts> tris;
     std::vector<uint32_t> tri_indices;
-    std::vector<WideNode> blas;
+    std::vector<QNode> blas;
     std::vector<MeshDev> meshes(s.num_meshes);
     std::vector<uint32_t> mesh_root(s.num_meshes);
-    uint32_t max_blas_depth = 0;
+    std::vector<uint32_t> mesh_words(s.num_meshes, 0u);   // worst-case traversal-stack words inside the mesh's BLAS
+    const char *qenv = getenv("LUPIN_QNODES");
+    const bool use_pairs = !(qenv && strcmp(qenv, "0") == 0);   // LUPIN_QNODES=0: every side SINGLE = one binary level per fetch (A/B runs)
     for (uint32_t mi = 0; mi < s.num_meshes; mi++)
     {
         const LupinMeshDesc &m = s.meshes[mi];
@@ -614,100 +710,74 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
             tri_indices.push_back(0); tri_indices.push_back(0); tri_indices.push_back(0);
             continue;
         }
-        // node index -> child reference
-        std::vector<uint32_t> ref(m.num_bvh_nodes);
-        uint32_t wide_base = (uint32_t)blas.size(), wide_count = 0;
         for (uint32_t n = 0; n < m.num_bvh_nodes; n++)
         {
             const LupinBvhNode &nd = m.bvh_nodes[n];
             if (nd.tri_count > 0)
             {
                 if ((uint64_t)nd.tri_begin_or_first_child + nd.tri_count > ntris) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "BLAS leaf range out of bounds"); }
-                ref[n] = REF_LEAF | (md.tri_offset + nd.tri_begin_or_first_child);
                 uint32_t last = md.tri_offset + nd.tri_begin_or_first_child + nd.tri_count - 1;
                 tris[last].v0.w = host_u2f(LEAF_END_BITS);
             }
-            else
-            {
-                if ((uint64_t)nd.tri_begin_or_first_child + 1 >= m.num_bvh_nodes) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "BLAS child index out of bounds"); }
-                ref[n] = wide_base + wide_count++;
-            }
+            else if ((uint64_t)nd.tri_begin_or_first_child + 1 >= m.num_bvh_nodes) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "BLAS child index out of bounds"); }
         }
-        blas.resize(wide_base + wide_count);
-        for (uint32_t n = 0; n < m.num_bvh_nodes; n++)
-        {
-            const LupinBvhNode &nd = m.bvh_nodes[n];
-            if (nd.tri_count > 0) continue;
-            const LupinBvhNode &l = m.bvh_nodes[nd.tri_begin_or_first_child];
-            const LupinBvhNode &r = m.bvh_nodes[nd.tri_begin_or_first_child + 1];
-            WideNode w;
-            w.a = make_float4(l.aabb_min[0], l.aabb_min[1], l.aabb_min[2], l.aabb_max[0]);
-            w.b = make_float4(l.aabb_max[1], l.aabb_max[2], r.aabb_min[0], r.aabb_min[1]);
-            w.c = make_float4(r.aabb_min[2], r.aabb_max[0], r.aabb_max[1], r.aabb_max[2]);
-            w.d = make_uint4(ref[nd.tri_begin_or_first_child], ref[nd.tri_begin_or_first_child + 1], 0u, 0u);
-            blas[ref[n]] = w;
-        }
-        mesh_root[mi] = ref[0];
-        const uint32_t bd = blas_depth(m.bvh_nodes, m.num_bvh_nodes);
-        if (bd == 0xFFFFFFFFu) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "BLAS is not a tree"); }
-        max_blas_depth = std::max(max_blas_depth, bd);
+        if (blas_depth(m.bvh_nodes, m.num_bvh_nodes) == 0xFFFFFFFFu) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "BLAS is not a tree"); }
+        mesh_root[mi] = 0u;   // converted below
     }
 
     // ---- TLAS ----
-    std::vector<WideNode> tlas;
+    std::vector<QNode> tlas;
     uint32_t tlas_root = REF_LEAF;
-    uint32_t tlas_depth = 0;
+    uint32_t stack_words = 1;
     if (s.num_tlas_nodes > 0)
     {
-        std::vector<uint32_t> ref(s.num_tlas_nodes);
-        uint32_t wide_count = 0;
         for (uint32_t n = 0; n < s.num_tlas_nodes; n++)
         {
             const LupinTlasNode &nd = s.tlas_nodes[n];
-            if (nd.left == 0)
-            {
-                if (nd.instance_idx >= s.num_instances) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "TLAS leaf instance out of range"); }
-                ref[n] = REF_LEAF | nd.instance_idx;
-            }
-            else
-            {
-                if (nd.left >= s.num_tlas_nodes || nd.right >= s.num_tlas_nodes) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "TLAS child out of range"); }
-                ref[n] = wide_count++;
-            }
+            if (nd.left == 0) { if (nd.instance_idx >= s.num_instances) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "TLAS leaf instance out of range"); } }
+            else if (nd.left >= s.num_tlas_nodes || nd.right >= s.num_tlas_nodes) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "TLAS child out of range"); }
         }
-        tlas.resize(wide_count);
-        for (uint32_t n = 0; n < s.num_tlas_nodes; n++)
-        {
-            const LupinTlasNode &nd = s.tlas_nodes[n];
-            if (nd.left == 0) continue;
-            const LupinTlasNode &l = s.tlas_nodes[nd.left];
-            const LupinTlasNode &r = s.tlas_nodes[nd.right];
-            WideNode w;
-            w.a = make_float4(l.aabb_min[0], l.aabb_min[1], l.aabb_min[2], l.aabb_max[0]);
-            w.b = make_float4(l.aabb_max[1], l.aabb_max[2], r.aabb_min[0], r.aabb_min[1]);
-            w.c = make_float4(r.aabb_min[2], r.aabb_max[0], r.aabb_max[1], r.aabb_max[2]);
-            w.d = make_uint4(ref[nd.left], ref[nd.right], 0u, 0u);
-            tlas[ref[n]] = w;
-        }
-        tlas_root = ref[0];
-        // depth from the root (bounded walk: a malformed cyclic TLAS is rejected)
-        std::vector<std::pair<uint32_t, uint32_t>> st;
-        st.push_back({0u, 0u});
+        // bounded walk from the root: a malformed cyclic TLAS is rejected
+        std::vector<uint32_t> st;
+        st.push_back(0u);
         uint64_t visited = 0;
         while (!st.empty())
         {
-            auto [n, d] = st.back();
+            const uint32_t n = st.back();
             st.pop_back();
             if (++visited > (uint64_t)s.num_tlas_nodes * 2 + 2) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "TLAS is not a tree"); }
-            if (s.tlas_nodes[n].left != 0)
-            {
-                tlas_depth = std::max(tlas_depth, d + 1);
-                st.push_back({s.tlas_nodes[n].left, d + 1});
-                st.push_back({s.tlas_nodes[n].right, d + 1});
-            }
+            if (s.tlas_nodes[n].left != 0) { st.push_back(s.tlas_nodes[n].left); st.push_back(s.tlas_nodes[n].right); }
         }
     }
-    sc->stack_entries = tlas_depth + max_blas_depth + 1;
+    // both levels -> QNodes; if pairing makes the worst-case stack too large for the kernels that keep it all in LDS, fall
+    // back to one binary level per node (every side SINGLE: the worst case is then the hierarchy's depth)
+    auto convert = [&](bool pairs) {
+        blas.clear(); tlas.clear();
+        for (uint32_t mi = 0; mi < s.num_meshes; mi++)
+        {
+            const LupinMeshDesc &m = s.meshes[mi];
+            if (m.num_indices / 3 == 0 || m.num_bvh_nodes == 0) continue;   // degenerate mesh: its leaf reference was set above
+            BlasTree bt; bt.nodes = m.bvh_nodes; bt.tri_offset = meshes[mi].tri_offset;
+            const QOut root = build_qnodes(bt, 0u, blas, 0u, pairs);
+            mesh_root[mi] = root.ref;
+            mesh_words[mi] = root.words;
+        }
+        stack_words = 1;
+        if (s.num_tlas_nodes > 0)
+        {
+            TlasTree tt; tt.nodes = s.tlas_nodes; tt.instances = s.instances; tt.mesh_words = mesh_words.data();
+            const QOut root = build_qnodes(tt, 0u, tlas, 0u, pairs);
+            tlas_root = root.ref;
+            stack_words = root.words + 1;
+        }
+        for (uint32_t w : mesh_words) stack_words = std::max(stack_words, w + 1);   // light-pdf marching walks single BLASes
+        stack_words += 4;   // q_visit writes up to four words above the stack top before deciding to keep them
+    };
+    convert(use_pairs);
+    if (use_pairs && stack_words > 128u) convert(false);
+    if (tris.size() >= REF_DEFERRED || blas.size() >= REF_DEFERRED || tlas.size() >= REF_DEFERRED || s.num_instances >= REF_DEFERRED)
+    { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "scene too large: child references hold 30 bits"); }
+    sc->stack_entries = stack_words;
 
     // ---- instances ----
     std::vector<InstanceDev> instances(s.num_instances);
@@ -770,6 +840,9 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
     // Conservative world-space bounding sphere of every light instance (all mesh vertices through the inverse of the
     // stored world->local rows, in double, radius padded): lights_pdf skips lights whose sphere the ray cannot reach.
     // A skipped light contributes exactly +0.0f in the reference's sum, so results do not change.
+    uint32_t light_words = 1;
+    for (uint32_t i = 0; i < s.num_lights; i++) light_words = std::max(light_words, mesh_words[s.instances[s.lights[i].instance_idx].mesh_idx] + 5);
+    sc->light_stack_entries = light_words;
     std::vector<float4> light_bounds(s.num_lights);
     for (uint32_t i = 0; i < s.num_lights; i++)
     {
@@ -811,16 +884,16 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
     std::vector<float4> geo_blob;
     uint32_t off_blas = 0, off_tris = 0, off_inst = 0;
     {
-        const size_t bytes = tlas.size() * 64 + blas.size() * 64 + tris.size() * 48 + instances.size() * 64;
+        const size_t bytes = tlas.size() * 128 + blas.size() * 128 + tris.size() * 48 + instances.size() * 64;
         if (bytes > 0 && bytes <= LP_GEO_LDS_LIMIT)
         {
             auto append = [&](const void *p, size_t nbytes) {
                 const float4 *f = reinterpret_cast<const float4 *>(p);
                 geo_blob.insert(geo_blob.end(), f, f + nbytes / 16);
             };
-            append(tlas.data(), tlas.size() * 64);
+            append(tlas.data(), tlas.size() * 128);
             off_blas = (uint32_t)geo_blob.size();
-            append(blas.data(), blas.size() * 64);
+            append(blas.data(), blas.size() * 128);
             off_tris = (uint32_t)geo_blob.size();
             append(tris.data(), tris.size() * 48);
             off_inst = (uint32_t)geo_blob.size();
@@ -1122,15 +1195,35 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
     const uint32_t blocks_per_shard = (blocks_needed + LP_SHARDS - 1) / LP_SHARDS;
     const uint32_t blocks = blocks_per_shard * LP_SHARDS;
     ln->pb.shard_cap = blocks_per_shard * LP_BLOCK;
-    const uint32_t stack_words = scene->stack_entries * LP_BLOCK;
     const bool lds_geo = scene->dev.geo_blob_words && ctx->lds_geometry;
-    const size_t lds = (size_t)stack_words * sizeof(uint32_t) + (lds_geo ? (size_t)scene->dev.geo_blob_words * 16 : 0);
-    if (lds > 160 * 1024) return fail(LUPIN_ERR_INVALID_ARGUMENT, "BVH too deep for the LDS traversal stack");
+    StackPlan plan;
+    plan.full_words = scene->stack_entries;
+    plan.light_words = scene->light_stack_entries;
+    plan.persist_words = ctx->persist_lds_words;   // an LDS ring (power of two); the deep tail lives in Lane::stack_overflow
+    plan.blob_bytes = lds_geo ? scene->dev.geo_blob_words * 16u : 0u;
+    const bool persistent_path = use_persistent(ctx, lds_geo);
+    const size_t lds = persistent_path ? plan.lds(plan.persist_words) : plan.lds(plan.full_words);   // the closest-hit kernel's
+    if (plan.lds(persistent_path && (pathtrace_type == LUPIN_PATHTRACE_STANDARD || pathtrace_type == LUPIN_PATHTRACE_NAIVE || ctx->persistent_shadow)
+                     ? std::max(plan.persist_words, plan.light_words) : plan.full_words) > 160 * 1024)
+        return fail(LUPIN_ERR_INVALID_ARGUMENT, "BVH too deep for the LDS traversal stack");
 
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (ctx->timing) { t0 = get_event(ctx); t1 = get_event(ctx); hipEventRecord(t0, st); }
 
     const uint32_t pblocks = persistent_grid(ctx, scene, pathtrace_type, lds_geo, lds);
+    if (pblocks)
+    {
+        // deep tail of the persistent tracer's stacks: (worst case - words kept in LDS) per resident thread
+        const uint64_t need = (uint64_t)(plan.full_words + 16u) * pblocks * LP_BLOCK;
+        if (need > ln->overflow_capacity)
+        {
+            HIP_TRY(hipStreamSynchronize(st));
+            if (ln->stack_overflow) { hipFree(ln->stack_overflow); ln->stack_overflow = nullptr; ln->overflow_capacity = 0; }
+            HIP_TRY(hipMalloc((void **)&ln->stack_overflow, need * sizeof(uint32_t)));
+            ln->overflow_capacity = need;
+            ln->pb_generation++;
+        }
+    }
     hipLaunchKernelGGL(k_set_params, dim3(1), dim3(1), 0, st, fp, ln->d_fp);
     if (ctx->use_graph && !ctx->timing && !ctx->counting)
     {
@@ -1138,7 +1231,8 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
         // (scene, dispatch size, integrator, buffers) and replayed: one graph launch instead of 2-4 launches per iteration.
         Lane::GraphKey key;
         key.scene_id = scene->id; key.pb_generation = ln->pb_generation; key.n = n; key.blocks = blocks; key.type = pathtrace_type;
-        key.iterations = iterations; key.stack_words = stack_words; key.lds = (uint32_t)lds; key.pblocks = pblocks;
+        key.iterations = iterations; key.full_words = plan.full_words; key.light_words = plan.light_words; key.persist_words = plan.persist_words;
+        key.blob_bytes = plan.blob_bytes; key.pblocks = pblocks;
         key.refill_min = ctx->refill_min; key.node_steps = ctx->node_steps; key.persistent = ctx->persistent_extend;
         key.persistent_shadow = ctx->persistent_shadow ? 1 : 0; key.lds_geometry = lds_geo ? 1 : 0;
         const bool have = ln->graph_exec && key == ln->graph_key;
@@ -1147,7 +1241,7 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
             // the lane holds a graph of another shape and this one is new (shapes alternate, e.g. edge tiles): capturing
             // costs about a millisecond, so launch directly and re-capture only if the shape repeats
             ln->seen_key = key;
-            HIP_TRY(enqueue_wavefront(ctx, ln, scene, pathtrace_type, lds_geo, n, blocks, pblocks, lds, stack_words, iterations));
+            HIP_TRY(enqueue_wavefront(ctx, ln, scene, pathtrace_type, lds_geo, n, blocks, pblocks, plan, iterations));
         }
         else
         {
@@ -1156,7 +1250,7 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
                 if (ln->graph_exec) { hipGraphExecDestroy(ln->graph_exec); ln->graph_exec = nullptr; }
                 if (ln->graph) { hipGraphDestroy(ln->graph); ln->graph = nullptr; }
                 HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-                hipError_t ce = enqueue_wavefront(ctx, ln, scene, pathtrace_type, lds_geo, n, blocks, pblocks, lds, stack_words, iterations);
+                hipError_t ce = enqueue_wavefront(ctx, ln, scene, pathtrace_type, lds_geo, n, blocks, pblocks, plan, iterations);
                 hipError_t ee = hipStreamEndCapture(st, &ln->graph);
                 if (ce != hipSuccess || ee != hipSuccess) return fail(LUPIN_ERR_HIP, std::string("graph capture: ") + hipGetErrorString(ce != hipSuccess ? ce : ee));
                 HIP_TRY(hipGraphInstantiate(&ln->graph_exec, ln->graph, nullptr, nullptr, 0));
@@ -1168,7 +1262,7 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
         }
     }
     else
-        HIP_TRY(enqueue_wavefront(ctx, ln, scene, pathtrace_type, lds_geo, n, blocks, pblocks, lds, stack_words, iterations));
+        HIP_TRY(enqueue_wavefront(ctx, ln, scene, pathtrace_type, lds_geo, n, blocks, pblocks, plan, iterations));
     // The frames meet here: the resolve reads prev_frame and overwrites render_target, so it is ordered after everything
     // enqueued so far on the other lane (the previous call's resolve) and, for lane 1, on the primary stream (texture
     // uploads / copies).  The path state itself is private to the lane.
@@ -1269,7 +1363,7 @@ int lupin_hip_stats_get(LupinContext *ctx, LupinStats *out)
     {
         unsigned long long w[LP_WORK_WORDS];
         HIP_TRY(hipMemcpy(w, ctx->lanes[l].work_counters, sizeof(w), hipMemcpyDeviceToHost));
-        for (int m = 0; m < 3; m++) { out->node_visits[m] += w[3 * m + 0]; out->tri_tests[m] += w[3 * m + 1]; out->instance_entries[m] += w[3 * m + 2]; }
+        for (int m = 0; m < 3; m++) { out->node_visits[m] += w[8 * m + 0]; out->tri_tests[m] += w[8 * m + 1]; out->instance_entries[m] += w[8 * m + 2]; out->node_fetches[m] += w[8 * m + 3]; for (int k = 0; k < 4; k++) out->sched[m][k] += w[8 * m + 4 + k]; }
     }
     out->extend_launches = ctx->extend_launches;
     auto sum = [](const std::vector<std::pair<hipEvent_t, hipEvent_t>> &v) {

@@ -259,12 +259,12 @@ __device__ __forceinline__ void trace_alpha(const Geo &geo, const SceneDev &sc, 
 }
 
 // Work counters (bench.py's roofline numerator, lupin_hip_stats_reset(ctx, 2)): the COUNT instantiations of the tracing
-// kernels wrap their geometry accessor in GeoTally and add the wave's totals to work[3 * mode + {0 nodes, 1 triangles, 2 instances}].
+// kernels wrap their geometry accessor in GeoTally and add the wave's totals to work[4 * mode + {0 nodes, 1 triangles, 2 instances, 3 node fetches}].
 // All 64 lanes must be active when this is called.
-__device__ __forceinline__ void tally_flush(const uint32_t (&tally)[3], unsigned long long *work)
+__device__ __forceinline__ void tally_flush(const uint32_t (&tally)[8], unsigned long long *work)
 {
     #pragma unroll
-    for (int k = 0; k < 3; k++)
+    for (int k = 0; k < 8; k++)
     {
         uint32_t v = tally[k];
         #pragma unroll
@@ -288,7 +288,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launc
     const FrameParams fp = *fpp;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     const auto base_geo = make_geo<LDSGEO>(sc, lds_stack, stack_words);
-    uint32_t tally[3] = {0u, 0u, 0u};
+    uint32_t tally[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     const auto geo = with_tally<COUNT>(base_geo, tally);
     const uint32_t shard = blockIdx.x % LP_SHARDS;
     const uint32_t count = pb.counts[iter * LP_SHARDS + shard];
@@ -339,13 +339,16 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launc
 template <int TYPE, bool LDSGEO, int MODE, bool COUNT>
 __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, const FrameParams *__restrict__ fpp, PathBuffers pb, uint32_t iter,
                                                                 unsigned long long *shard_stats, uint32_t refill_min, uint32_t stack_words, uint32_t nsteps,
-                                                                unsigned long long *work)
+                                                                unsigned long long *work, uint32_t *stack_overflow)
 {
     const FrameParams fp = *fpp;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     const auto base_geo = make_geo<LDSGEO>(sc, lds_stack, stack_words);
-    uint32_t tally[3] = {0u, 0u, 0u};
+    uint32_t tally[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     const auto geo = with_tally<COUNT>(base_geo, tally);
+    RingStack stk;   // stack_words / LP_BLOCK = ring size, a power of two >= 32 (host)
+    stk.lds = lds_stack + threadIdx.x; stk.mask = stack_words / LP_BLOCK - 1u; stk.floor = 0u;
+    stk.threads = gridDim.x * LP_BLOCK; stk.overflow = stack_overflow + (size_t)blockIdx.x * LP_BLOCK + threadIdx.x;
     static_assert(LP_SHARDS <= LP_BLOCK && 256 % LP_SHARDS == 0, "block 0 books one shard per thread; 64-block grids hold whole waves per shard");
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t *counts = pb.counts + (size_t)iter * LP_SHARDS;
@@ -380,15 +383,17 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
     auto start_traversal = [&]() {
         inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         co = o; cd = d; cinv = inv_d;
-        sp = 0; blas_base = 0xFFFFFFFFu;
+        sp = 0; blas_base = 0xFFFFFFFFu; stk.floor = 0u;
         cur = sc.num_instances ? sc.tlas_root : REF_DONE;
         best.t = LP_F32_MAX; best.u = 0.0f; best.v = 0.0f; best.tri = 0u; best.inst = HIT_MISS;
     };
     auto pop = [&]() {
-        if (sp == blas_base) { blas_base = 0xFFFFFFFFu; co = o; cd = d; cinv = inv_d; }
-        if (sp == 0) { cur = REF_DONE; return; }
-        sp--;
-        cur = lds_stack[sp * LP_BLOCK + tid];
+        if (blas_base != 0xFFFFFFFFu)
+        {
+            if (q_pop(geo, stk, sp, blas_base, cur, best.t)) return;
+            blas_base = 0xFFFFFFFFu; co = o; cd = d; cinv = inv_d;   // the BLAS is exhausted: back to the world ray
+        }
+        if (!q_pop(geo, stk, sp, 0u, cur, best.t)) cur = REF_DONE;
     };
 
     // Phase scheduling: a lane is at an internal node (N), a TLAS leaf = instance entry (I), a triangle of a BLAS leaf (T),
@@ -405,10 +410,12 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
         const uint32_t cE = (uint32_t)__popcll(idle);
         const uint32_t cN = (uint32_t)__popcll(__ballot(isN)), cI = (uint32_t)__popcll(__ballot(isI));
         const uint32_t cT = (uint32_t)__popcll(__ballot(isT)), cF = (uint32_t)__popcll(__ballot(isF));
+        if (COUNT && lane == 0u) tally[7]++;   // scheduling rounds of this wave
 
         if (cE >= refill_min && next_pos < n_mine)
         {
             // ---- refill empty lanes ----
+            if (COUNT && lane == 0u) tally[6]++;
             const uint32_t my_rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             const uint32_t take = min(cE, n_mine - next_pos);
             const bool got = !active && my_rank < take;
@@ -467,25 +474,18 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
             {
                 const bool n = active && !(cur & REF_LEAF);
                 if (r > 0 && (r >= nsteps || (uint32_t)__popcll(__ballot(n)) * 2u < cN)) break;
+                if (COUNT && lane == 0u) tally[4]++;   // node steps of this wave
                 if (n)
                 {
-                    const NodeRegs nd = geo.node(blas_base != 0xFFFFFFFFu, cur);
-                    float ld = slab_dst(co, cinv, nd.a.x, nd.a.y, nd.a.z, nd.a.w, nd.b.x, nd.b.y);
-                    float rd = slab_dst(co, cinv, nd.b.z, nd.b.w, nd.c.x, nd.c.y, nd.c.z, nd.c.w);
-                    bool left_first = ld <= rd;
-                    bool push_l = ld < best.t, push_r = rd < best.t;
-                    uint32_t near_ref = left_first ? nd.left : nd.right;
-                    uint32_t far_ref = left_first ? nd.right : nd.left;
-                    bool push_near = left_first ? push_l : push_r;
-                    bool push_far = left_first ? push_r : push_l;
-                    if (push_far) { lds_stack[sp * LP_BLOCK + tid] = far_ref; sp++; }
-                    if (push_near) cur = near_ref; else pop();
+                    const QRegs q = geo.qnode(blas_base != 0xFFFFFFFFu, cur);
+                    if (!q_visit(geo, q, stk, sp, cur, best.t, co, cinv)) pop();
                 }
             }
         }
         else if (cT >= cI && cT >= cF)
         {
             // ---- T: one triangle of a BLAS leaf, first-found wins ties (strict <) ----
+            if (COUNT && lane == 0u) tally[5]++;   // triangle steps of this wave
             if (isT)
             {
                 const uint32_t ti = cur & ~REF_LEAF;
@@ -557,7 +557,7 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
             }
         }
     }
-    if (COUNT) tally_flush(tally, work + 3 * MODE);   // the loop ends wave-uniformly: all lanes are here
+    if (COUNT) tally_flush(tally, work + 8 * MODE);   // the loop ends wave-uniformly: all lanes are here
 }
 
 // clamp_radiance (pathtracer.wgsl:1774-1783)
