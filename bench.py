@@ -18,8 +18,8 @@ was built and tested against.  Launch with `python -m torch.distributed.run --np
 N rank processes itself.
 
 The JSON line also carries (rank 0, N = 1)
-  roofline      dominant kernel: bytes it requests per path-bounce in THIS build's layout after light culling (128 B per
-                two-level node fetch, 48 B per triangle test, 64 B per instance entry, 56 B of path state; counted on the device by
+  roofline      dominant kernel: bytes it requests per path-bounce in THIS build's layout after light culling (64 B per
+                node visit, 48 B per triangle test, 64 B per instance entry, 56 B of path state; counted on the device by
                 the kernel's work-counting instantiation) x units per launch / its hipEvent-measured launch time, against
                 the nominal 8 TB/s and a device-copy peak measured in the same run; `traffic` / `l2_hit` from the PMC
                 passes committed under profiles/;
@@ -86,13 +86,13 @@ def camera_for(api, cam, width, height, keep_aspect=False):
 def own_layout_bytes(kst, mode=0):
     """Bytes the tracing kernel requests per path-bounce in this build's layout, from its device-side work counters."""
     u = max(1, kst["path_bounces"])
-    n, t, i, f = kst["node_visits"][mode] / u, kst["tri_tests"][mode] / u, kst["instance_entries"][mode] / u, kst["node_fetches"][mode] / u
+    n, t, i = kst["node_visits"][mode] / u, kst["tri_tests"][mode] / u, kst["instance_entries"][mode] / u
     sch = kst["sched"][mode]
-    return {"binary_node_visits": n, "node_fetches": f, "tri_tests": t, "instance_entries": i,
-            "lanes_per_node_step": kst["node_fetches"][mode] / max(1, sch[0]), "lanes_per_tri_step": kst["tri_tests"][mode] / max(1, sch[1]),
+    return {"node_visits": n, "tri_tests": t, "instance_entries": i,
+            "lanes_per_node_step": kst["node_visits"][mode] / max(1, sch[0]), "lanes_per_tri_step": kst["tri_tests"][mode] / max(1, sch[1]),
             "node_steps_per_unit_x64": 64.0 * sch[0] / u, "tri_steps_per_unit_x64": 64.0 * sch[1] / u, "rounds_per_unit_x64": 64.0 * sch[3] / u,
             "refills_per_unit_x64": 64.0 * sch[2] / u,
-            "bytes_per_unit": 128.0 * f + 48.0 * t + 64.0 * i + PATH_STATE_BYTES_EXTEND}
+            "bytes_per_unit": 64.0 * n + 48.0 * t + 64.0 * i + PATH_STATE_BYTES_EXTEND}
 
 
 def pmc_record(workload_key):
@@ -162,7 +162,7 @@ def measure_single_gpu(api, ctx, scene, cam, width, height, bounces, spp, steps,
             "bytes_per_unit": own["bytes_per_unit"], "bytes_per_unit_terms": {k: own[k] for k in own if k != "bytes_per_unit"},
             "units_per_launch": units_per_launch, "avg_launch_us": avg_s * 1e6, "launches_timed": launches,
             "share_of_frame_time": kst["extend_ms"] / kst["total_ms"] if kst["total_ms"] else None,
-            "definition": "bytes REQUESTED by the closest-hit kernel in this build's layout after culling (128 B/two-level node fetch + 48 B/triangle "
+            "definition": "bytes REQUESTED by the closest-hit kernel in this build's layout after culling (64 B/node visit + 48 B/triangle "
                           "test + 64 B/instance entry + 56 B path state, device-counted) x units per launch / hipEvent launch time",
         }
         if scene_is_lds_resident(scene):

@@ -435,14 +435,13 @@ typedef struct LupinStats {
     double total_ms;            /* whole pathtrace_scene device time (timing on) */
     /* LUPIN_STATS_WORK_COUNTERS: work done by the tracing kernels in this build's layout, per tracing mode
      * [0] closest hit of the integrator loop, [1] MIS / Direct shadow rays, [2] light-pdf marching:
-     * internal nodes of the reference's binary hierarchy visited (= the oracle's box tests / 2), triangle tests (one
-     * 48-byte record each), instance entries (64 bytes), and fetches of this build's 128-byte two-level nodes */
+     * internal-node visits (= the oracle's box tests / 2; one 64-byte node fetch each), triangle tests (one 48-byte
+     * record each), instance entries (64 bytes) */
     uint64_t node_visits[3];
     uint64_t tri_tests[3];
     uint64_t instance_entries[3];
-    uint64_t node_fetches[3];
     /* persistent tracer, per mode: wave-level node steps, triangle steps, refills, scheduling rounds (diagnostics:
-     * lanes per node step = node_fetches / sched[.][0]) */
+     * lanes per node step = node_visits / sched[.][0]) */
     uint64_t sched[3][4];
 } LupinStats;
 enum LupinStatsMode {

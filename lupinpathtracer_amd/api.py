@@ -16,6 +16,7 @@ Where the reference panics (assert!/panic!), these raise (`LupinError` for ABI e
 `AssertionError`/`ValueError` for host-side validation).
 """
 import ctypes as C
+import os
 import enum
 from dataclasses import dataclass, field
 from typing import List, Optional
@@ -505,6 +506,8 @@ def build_lights(scene: SceneCPU, envs_info: List[EnvMapInfo]):
     for i, env in enumerate(scene.environments):
         info = envs_info[i]
         tex = np.ascontiguousarray(info.data, np.float32).reshape(info.height, info.width, 4)
+        if os.environ.get("LUPIN_EXPERIMENT_ENV_F16_WEIGHTS") == "1":   # tools/env_residual.py: weights from the f16 texels the shader samples
+            tex = np.ascontiguousarray(tex.astype(np.float16).astype(np.float32))
         scale = np.ascontiguousarray(env["emission"], np.float32)
         weights = np.zeros(info.width * info.height, np.float32)
         lib().lupin_env_light_weights(ptr(tex), info.width, info.height, ptr(scale), ptr(weights))

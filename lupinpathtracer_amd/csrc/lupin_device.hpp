@@ -32,36 +32,24 @@ namespace lpd {
 // ------------------------------------------------------------------------------------------------
 
 // Child references used by both levels of the hierarchy.
-//   BLAS: bit31 set   -> leaf, low bits = global index of its first triangle; the leaf ends at
+//   BLAS: bit31 set   -> leaf, low 31 bits = global index of its first triangle; the leaf ends at
 //                        the first triangle whose v0.w carries LEAF_END
-//         bit31 clear -> index of a QNode
-//   TLAS: bit31 set   -> leaf, low bits = instance index
-// Bit 30 is reserved (REF_DEFERRED tags a parked node on the traversal stack), so payloads are < 2^30.
+//         bit31 clear -> index of a WideNode
+//   TLAS: bit31 set   -> leaf, low 31 bits = instance index
 constexpr uint32_t REF_LEAF = 0x80000000u;
-constexpr uint32_t REF_DEFERRED = 0x40000000u;
 constexpr uint32_t LEAF_END_BITS = 1u;
 
-// One 128-byte record = TWO levels of the reference's binary hierarchy: the internal node P it stands for, described by
-// the boxes of P's grandchildren.  Measured on MI355X (tools/calib/gather_probe.hip): the memory system serves ~55 G
-// random requests per second whether a request is 64 or 128 aligned bytes, and the tracer is bound by its chain of
-// dependent node fetches -- so a fetch should carry two levels.  The reference reads node + 2 children (3 x 32/48 B)
-// per level (bvh_custom.wgsl:47-51, :234-240).
-//
-// Side A = P's left child L, side B = P's right child R.  A side is either
-//   a PAIR   (slots 2s, 2s+1 = the boxes and references of the child's two children): used when the child is internal
-//            and its box equals the union of its children's boxes bit for bit -- true for the reference's builders
-//            (data_structures.rs:196-641: a node's box is the min / max over its triangles, a TLAS node's the union of
-//            the merged pair) and checked per node at upload; the child's own box is then min / max of the pair, exactly;
-//   or SINGLE (slot 2s = the child's own box and reference): the child is a leaf, or its box is not that union.
-// The traversal visits nodes in exactly the reference's order (near child first, far child parked, children tested
-// against the closest hit at the moment their parent is visited): a pair's distances are computed when P is fetched and,
-// for the far side, parked on the stack with the two references (the binary traversal would compute the same numbers
-// when it pops that child: they depend on the ray and the boxes only) -- see q_visit / q_pop.
-struct QNode
+// One internal node = both children's boxes + references, one 64-byte line.  The reference
+// reads the node (32/48 B) and then both children (2 x 32/48 B) per visit
+// (bvh_custom.wgsl:47-51, :234-240); here one aligned 64 B fetch carries everything the visit
+// needs.
+struct WideNode
 {
-    float4 w[8];   // w[0..5]: 4 slots x {lo.xyz, hi.xyz}; w[6]: 4 references (slot 1 / slot 3 = REF_NONE: that side is SINGLE); w[7] unused
+    float4 a;  // l.min.x l.min.y l.min.z l.max.x
+    float4 b;  // l.max.y l.max.z r.min.x r.min.y
+    float4 c;  // r.min.z r.max.x r.max.y r.max.z
+    uint4 d;   // left_ref right_ref 0 0
 };
-constexpr uint32_t REF_NONE = 0xFFFFFFFFu;
 
 // Triangles pre-gathered in BLAS leaf order: no index indirection during traversal
 // (the reference does verts_pos[indices[i*3+k]], bvh_custom.wgsl:217-219).
@@ -101,8 +89,8 @@ struct AliasRange { uint32_t offset, count; };
 
 struct SceneDev
 {
-    const QNode *tlas;           uint32_t tlas_root;   // child reference
-    const QNode *blas;
+    const WideNode *tlas;        uint32_t tlas_root;   // child reference
+    const WideNode *blas;
     const TriVerts *tris;
     const uint32_t *tri_indices; // 3 per global triangle, mesh-local vertex ids
     const InstanceDev *instances;
@@ -258,30 +246,19 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const v4f *lds_v4p;
 constexpr uint32_t LP_GEO_LDS_LIMIT = 24 * 1024;
 
-struct QRegs { float b[24]; uint32_t r[4]; };   // a QNode in registers: b[6 * slot + {lo.xyz, hi.xyz}]
-
-LP_DEV void qregs_from(QRegs &q, const float4 (&w)[8])
-{
-    #pragma unroll
-    for (int k = 0; k < 6; k++) { q.b[4 * k + 0] = w[k].x; q.b[4 * k + 1] = w[k].y; q.b[4 * k + 2] = w[k].z; q.b[4 * k + 3] = w[k].w; }
-    q.r[0] = __float_as_uint(w[6].x); q.r[1] = __float_as_uint(w[6].y); q.r[2] = __float_as_uint(w[6].z); q.r[3] = __float_as_uint(w[6].w);
-}
+struct NodeRegs { float4 a, b, c; uint32_t left, right; };
 
 struct GeoGlobal
 {
-    const QNode *tlas, *blas;
+    const WideNode *tlas, *blas;
     const TriVerts *tris;
     const InstanceDev *instances;
-    LP_DEV QRegs qnode(bool in_blas, uint32_t i) const
+    LP_DEV NodeRegs node(bool in_blas, uint32_t i) const
     {
-        const float4 *p = (in_blas ? blas : tlas)[i].w;
-        float4 w[8];
-        #pragma unroll
-        for (int k = 0; k < 7; k++) w[k] = p[k];   // seven 16-byte loads of one 128-byte line
-        QRegs q; qregs_from(q, w);
-        return q;
+        const WideNode nd = (in_blas ? blas : tlas)[i];
+        NodeRegs r; r.a = nd.a; r.b = nd.b; r.c = nd.c; r.left = nd.d.x; r.right = nd.d.y;
+        return r;
     }
-    LP_DEV void side_visit() const {}                                    // a parked / near PAIR side is visited (no fetch)
     LP_DEV TriVerts tri(uint32_t i) const { return tris[i]; }           // a triangle TEST fetches through tri()
     LP_DEV TriVerts tri_fetch(uint32_t i) const { return tris[i]; }     // shading re-reads vertices through tri_fetch()
     LP_DEV InstanceDev inst(uint32_t i) const { return instances[i]; }
@@ -293,16 +270,13 @@ struct GeoLds
     lds_v4p base;
     uint32_t off_blas, off_tris, off_inst;
     static LP_DEV float4 f4(v4f v) { return make_float4(v.x, v.y, v.z, v.w); }
-    LP_DEV QRegs qnode(bool in_blas, uint32_t i) const
+    LP_DEV NodeRegs node(bool in_blas, uint32_t i) const
     {
-        lds_v4p p = base + (in_blas ? off_blas : 0u) + i * 8u;
-        float4 w[8];
-        #pragma unroll
-        for (int k = 0; k < 7; k++) w[k] = f4(p[k]);
-        QRegs q; qregs_from(q, w);
-        return q;
+        lds_v4p p = base + (in_blas ? off_blas : 0u) + i * 4u;
+        const v4f a = p[0], b = p[1], c = p[2], d = p[3];
+        NodeRegs r; r.a = f4(a); r.b = f4(b); r.c = f4(c); r.left = __float_as_uint(d.x); r.right = __float_as_uint(d.y);
+        return r;
     }
-    LP_DEV void side_visit() const {}
     LP_DEV TriVerts tri(uint32_t i) const
     {
         lds_v4p p = base + off_tris + i * 3u;
@@ -322,33 +296,30 @@ struct GeoLds
 };
 
 // pathtrace_scene_debug (renderer.rs:966, pathtracer.wgsl:457-503) counts box and triangle tests per pixel
-// (RAY_DEBUG_INFO, bvh_custom.wgsl:54,228,243): two box tests per visited internal node of the reference's binary
-// hierarchy.  A QNode fetch is the visit of the node it stands for, side_visit() the visit of one of its internal
-// children, so wrapping the accessor counts them without touching the traversal code.
+// (RAY_DEBUG_INFO, bvh_custom.wgsl:54,228,243).  Every traversal fetches internal nodes through node() and tested
+// triangles through tri(), so wrapping the accessor counts them without touching the traversal code.
 template <typename Base>
 struct GeoCounting
 {
     Base base;
     uint32_t *aabb_checks, *tri_checks;   // the calling thread's counters
     static constexpr bool kCounting = true;
-    LP_DEV QRegs qnode(bool in_blas, uint32_t i) const { *aabb_checks += 2u; return base.qnode(in_blas, i); }
-    LP_DEV void side_visit() const { *aabb_checks += 2u; }
+    LP_DEV NodeRegs node(bool in_blas, uint32_t i) const { *aabb_checks += 2u; return base.node(in_blas, i); }
     LP_DEV TriVerts tri(uint32_t i) const { *tri_checks += 1u; return base.tri(i); }
     LP_DEV TriVerts tri_fetch(uint32_t i) const { return base.tri(i); }
     LP_DEV InstanceDev inst(uint32_t i) const { return base.inst(i); }
 };
 
-// Work accounting of the tracing kernels (bench.py's roofline numerator): tally[0] = internal nodes of the reference's
-// binary hierarchy visited (equal to the oracle's box-test count / 2), [1] triangle tests (48-byte TriVerts each),
-// [2] instance entries (64-byte record each), [3] QNode fetches (128 bytes each).  The traversal code is untouched.
+// Work accounting of the traversal kernels in THIS build's layout (bench.py's roofline numerator): every internal-node
+// visit fetches one 64-byte WideNode, every triangle test one 48-byte TriVerts, every instance entry one 64-byte record.
+// Same idea as GeoCounting, with the calling thread's own three tallies; the traversal code is untouched.
 template <typename Base>
 struct GeoTally
 {
     Base base;
-    uint32_t *tally;
+    uint32_t *tally;   // [0] node visits, [1] triangle tests, [2] instance entries ([3..7]: scheduling diagnostics of the persistent tracer)
     static constexpr bool kCounting = false;   // light culling stays on: the tally is of the work actually done
-    LP_DEV QRegs qnode(bool in_blas, uint32_t i) const { tally[0] += 1u; tally[3] += 1u; return base.qnode(in_blas, i); }
-    LP_DEV void side_visit() const { tally[0] += 1u; }
+    LP_DEV NodeRegs node(bool in_blas, uint32_t i) const { tally[0] += 1u; return base.node(in_blas, i); }
     LP_DEV TriVerts tri(uint32_t i) const { tally[1] += 1u; return base.tri(i); }
     LP_DEV TriVerts tri_fetch(uint32_t i) const { return base.tri_fetch(i); }
     LP_DEV InstanceDev inst(uint32_t i) const { tally[2] += 1u; return base.inst(i); }
@@ -373,13 +344,12 @@ LP_DEV GeoLds geo_stage_lds(const SceneDev &sc, uint32_t *lds_words)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Traversal.  Per-lane stack of 32-bit words, word e of lane t at stack[e * LP_BLOCK + t] in LDS: bank = t mod 32 for
-// every depth, so pushes / pops never conflict inside a wave (the persistent tracer keeps only the first words there and
-// the rare deep tail in global memory, see k_extend_persistent).  A stack entry is either ONE word, a child reference
-// (the far child of a visited node: only the far one is ever stored, the near one is visited next without a round
-// trip, which is the visiting order of the reference's push-far-then-near / pop loop, bvh_custom.wgsl:63-94, :252-283),
-// or FOUR words, a parked PAIR side: [d0][d1][r1][r0 | REF_DEFERRED] (top).  Like the reference, a child is tested
-// against the best hit when its parent is visited, not again when it is popped.
+// Traversal.  Per-lane stack lives in LDS, entry e of lane t at stack[e * LP_BLOCK + t]:
+// bank = t mod 32 for every depth, so pushes/pops never conflict inside a wave.
+// Only the far child is ever stored (the near one is visited next without a round trip), which
+// is the visiting order of the reference's push-far-then-near / pop loop
+// (bvh_custom.wgsl:63-94, :252-283).  Like the reference, a child is tested against the best
+// hit when it is pushed, not again when it is popped.
 // ------------------------------------------------------------------------------------------------
 
 struct Closest
@@ -389,132 +359,39 @@ struct Closest
     uint32_t inst;
 };
 
-// LDS stack of the one-ray-per-lane kernels (sized for the scene's worst case at upload)
-struct LdsStack
-{
-    uint32_t *base;   // + threadIdx.x already applied
-    LP_DEV void write(uint32_t e, uint32_t v) const { base[e * LP_BLOCK] = v; }
-    LP_DEV uint32_t read(uint32_t e) const { return base[e * LP_BLOCK]; }
-    LP_DEV void before_push(uint32_t) {}
-    LP_DEV void before_pop(uint32_t) {}
-};
-
 // Stack of the persistent tracer: the newest `mask + 1` words of every lane live in an LDS ring (word e at ring slot
-// e & mask), older words in global memory.  The scene's worst case (computed at upload) can approach a hundred words, a
-// ray rarely holds more than two dozen: sizing LDS for the worst case would leave one block per CU resident, and that
-// kernel lives on the number of rays it keeps in flight.  Invariants: `floor` <= sp <= floor + mask + 1 (ring holds
-// [floor, floor + mask + 1)); before a visit that can push up to 5 words the oldest 16 are moved out if needed, before a
-// pop that can read 4 words they are brought back.  Both are rare, divergent slow paths.
+// e & mask, lane t at ring[slot * LP_BLOCK + t]: bank = t mod 32 at every depth), older words in global memory.  A scene's
+// worst case (its hierarchy depth, 39 for the bistro-class scene) sized the LDS stack of round 1 and with it the number of
+// resident blocks; a ray rarely holds more than a dozen entries, and this kernel lives on the number of rays it keeps in
+// flight.  Invariant: floor <= sp <= floor + mask + 1.  Before a push the oldest 8 words are moved out if the ring is
+// full, before a pop they are brought back if the ring is empty: rare, divergent slow paths.
 struct RingStack
 {
     uint32_t *lds;        // + threadIdx.x
     uint32_t *overflow;   // + global thread index; word e at overflow[e * threads]
     uint32_t mask, threads;
-    uint32_t floor;       // oldest word still in the ring (multiple of 16)
-    LP_DEV void write(uint32_t e, uint32_t v) const { lds[(e & mask) * LP_BLOCK] = v; }
-    LP_DEV uint32_t read(uint32_t e) const { return lds[(e & mask) * LP_BLOCK]; }
-    LP_DEV void before_push(uint32_t sp)
+    uint32_t floor;       // oldest word still in the ring (multiple of 8)
+    LP_DEV void push(uint32_t &sp, uint32_t v)
     {
-        if (sp + 5u > floor + mask + 1u)
+        if (sp == floor + mask + 1u)
         {
-            for (uint32_t k = 0; k < 16u; k++) overflow[(size_t)(floor + k) * threads] = read(floor + k);
-            floor += 16u;
+            for (uint32_t k = 0; k < 8u; k++) overflow[(size_t)(floor + k) * threads] = lds[((floor + k) & mask) * LP_BLOCK];
+            floor += 8u;
         }
+        lds[(sp & mask) * LP_BLOCK] = v;
+        sp++;
     }
-    LP_DEV void before_pop(uint32_t sp)
+    LP_DEV uint32_t pop(uint32_t &sp)
     {
-        if (floor != 0u && sp < floor + 4u)
+        if (sp == floor && floor != 0u)
         {
-            floor -= 16u;
-            for (uint32_t k = 0; k < 16u; k++) write(floor + k, overflow[(size_t)(floor + k) * threads]);
+            floor -= 8u;
+            for (uint32_t k = 0; k < 8u; k++) lds[((floor + k) & mask) * LP_BLOCK] = overflow[(size_t)(floor + k) * threads];
         }
+        sp--;
+        return lds[(sp & mask) * LP_BLOCK];
     }
 };
-
-// The visit of an internal node S whose two children (references r0 / r1) lie at box distances d0 / d1
-// (bvh_custom.wgsl:63-94 == :252-283): far child parked if closer than the best hit, near child next if closer, else
-// `cur` is left untouched and false is returned (the caller pops).
-template <typename Stk>
-LP_DEV bool visit_children(const Stk &stk, uint32_t &sp, uint32_t &cur, float best_t, uint32_t r0, uint32_t r1, float d0, float d1)
-{
-    const bool first0 = d0 <= d1;
-    const uint32_t near_ref = first0 ? r0 : r1, far_ref = first0 ? r1 : r0;
-    const float dn = first0 ? d0 : d1, df = first0 ? d1 : d0;
-    stk.write(sp, far_ref);               // written unconditionally (the slot is free), kept only if the far child qualifies
-    sp += df < best_t ? 1u : 0u;
-    const bool go = dn < best_t;
-    cur = go ? near_ref : cur;
-    return go;
-}
-
-// The visit of the node a fetched QNode stands for, plus -- when its near child is a PAIR side -- the visit of that child.
-// Returns false when nothing below is worth descending into (the caller pops).  Straight-line code: lanes of a wave
-// take every combination of single / pair and near / far, so everything is selected, and stack words are written
-// unconditionally above the stack top (free slots) and kept by advancing `sp`.
-template <typename Geo, typename Stk>
-LP_DEV bool q_visit(const Geo &geo, const QRegs &q, Stk &stk, uint32_t &sp, uint32_t &cur, float best_t, f3 co, f3 cinv)
-{
-    stk.before_push(sp);
-    const bool a_single = q.r[1] == REF_NONE, b_single = q.r[3] == REF_NONE;
-    const float d0 = slab_dst(co, cinv, q.b[0], q.b[1], q.b[2], q.b[3], q.b[4], q.b[5]);
-    const float d1 = slab_dst(co, cinv, q.b[6], q.b[7], q.b[8], q.b[9], q.b[10], q.b[11]);
-    const float d2 = slab_dst(co, cinv, q.b[12], q.b[13], q.b[14], q.b[15], q.b[16], q.b[17]);
-    const float d3 = slab_dst(co, cinv, q.b[18], q.b[19], q.b[20], q.b[21], q.b[22], q.b[23]);
-    // a PAIR side's own box = the exact union of its children's (checked at upload)
-    const float ua = slab_dst(co, cinv, __builtin_fminf(q.b[0], q.b[6]), __builtin_fminf(q.b[1], q.b[7]), __builtin_fminf(q.b[2], q.b[8]),
-                              __builtin_fmaxf(q.b[3], q.b[9]), __builtin_fmaxf(q.b[4], q.b[10]), __builtin_fmaxf(q.b[5], q.b[11]));
-    const float ub = slab_dst(co, cinv, __builtin_fminf(q.b[12], q.b[18]), __builtin_fminf(q.b[13], q.b[19]), __builtin_fminf(q.b[14], q.b[20]),
-                              __builtin_fmaxf(q.b[15], q.b[21]), __builtin_fmaxf(q.b[16], q.b[22]), __builtin_fmaxf(q.b[17], q.b[23]));
-    const float ld = a_single ? d0 : ua, rd = b_single ? d2 : ub;
-    const bool left_first = ld <= rd;
-    const bool push_l = ld < best_t, push_r = rd < best_t;
-    const bool push_near = left_first ? push_l : push_r, push_far = left_first ? push_r : push_l;
-    const bool n_single = left_first ? a_single : b_single, f_single = left_first ? b_single : a_single;
-    const uint32_t nr0 = left_first ? q.r[0] : q.r[2], nr1 = left_first ? q.r[1] : q.r[3];
-    const uint32_t fr0 = left_first ? q.r[2] : q.r[0], fr1 = left_first ? q.r[3] : q.r[1];
-    const float nd0 = left_first ? d0 : d2, nd1 = left_first ? d1 : d3;
-    const float fd0 = left_first ? d2 : d0, fd1 = left_first ? d3 : d1;
-    // park the far side: SINGLE = its reference, PAIR = [d0][d1][r1][r0 | tag]
-    stk.write(sp, f_single ? fr0 : __float_as_uint(fd0));
-    stk.write(sp + 1u, __float_as_uint(fd1));
-    stk.write(sp + 2u, fr1);
-    stk.write(sp + 3u, fr0 | REF_DEFERRED);
-    sp += push_far ? (f_single ? 1u : 4u) : 0u;
-    // the near side: SINGLE = continue with its reference, PAIR = visit that child now
-    if (push_near && !n_single) geo.side_visit();
-    const bool first0 = nd0 <= nd1;
-    const uint32_t g_near = first0 ? nr0 : nr1, g_far = first0 ? nr1 : nr0;
-    const float gdn = first0 ? nd0 : nd1, gdf = first0 ? nd1 : nd0;
-    const bool pair_now = push_near && !n_single;
-    stk.write(sp, g_far);
-    sp += (pair_now && gdf < best_t) ? 1u : 0u;
-    const bool go = push_near && (n_single || gdn < best_t);
-    cur = go ? (n_single ? nr0 : g_near) : cur;
-    return go;
-}
-
-// Pops until a reference to continue with is found: a plain entry is that reference; a parked PAIR side is visited now
-// (against the best hit as it stands now) and may itself leave nothing.  `floor` = the stack height below which this
-// traversal must not pop.  Returns false when the stack is exhausted down to `floor`.
-template <typename Geo, typename Stk>
-LP_DEV bool q_pop(const Geo &geo, Stk &stk, uint32_t &sp, uint32_t floor, uint32_t &cur, float best_t)
-{
-    while (sp != floor)
-    {
-        stk.before_pop(sp);
-        sp--;
-        const uint32_t w = stk.read(sp);
-        if (!(w & REF_DEFERRED)) { cur = w; return true; }
-        // parked PAIR side: [d0][d1][r1][r0 | tag]
-        const uint32_t r0 = w & ~REF_DEFERRED;
-        const uint32_t r1 = stk.read(sp - 1u);
-        const float d1 = __uint_as_float(stk.read(sp - 2u)), d0 = __uint_as_float(stk.read(sp - 3u));
-        sp -= 3u;
-        geo.side_visit();
-        if (visit_children(stk, sp, cur, best_t, r0, r1, d0, d1)) return true;
-    }
-    return false;
-}
 
 // Descend one BLAS (bvh_custom.wgsl:195-288) from `root`, updating `best` on strictly closer hits.
 // Returns true if any triangle of this mesh replaced the best hit.
@@ -522,7 +399,7 @@ template <typename Geo>
 LP_DEV bool blas_closest(const Geo &geo, uint32_t *stack, uint32_t sp_base, uint32_t root,
                          f3 o, f3 d, f3 inv_d, float eps, Closest &best)
 {
-    LdsStack stk; stk.base = stack + threadIdx.x;
+    const uint32_t tid = threadIdx.x;
     uint32_t sp = sp_base;
     uint32_t cur = root;
     bool replaced = false;
@@ -539,12 +416,29 @@ LP_DEV bool blas_closest(const Geo &geo, uint32_t *stack, uint32_t sp_base, uint
                 if (__float_as_uint(tv.v0.w) & LEAF_END_BITS) break;
                 ti++;
             }
-            if (!q_pop(geo, stk, sp, sp_base, cur, best.t)) break;
+            if (sp == sp_base) break;
+            sp--;
+            cur = stack[sp * LP_BLOCK + tid];
         }
         else
         {
-            const QRegs q = geo.qnode(true, cur);
-            if (!q_visit(geo, q, stk, sp, cur, best.t, o, inv_d) && !q_pop(geo, stk, sp, sp_base, cur, best.t)) break;
+            const NodeRegs nd = geo.node(true, cur);
+            float ld = slab_dst(o, inv_d, nd.a.x, nd.a.y, nd.a.z, nd.a.w, nd.b.x, nd.b.y);
+            float rd = slab_dst(o, inv_d, nd.b.z, nd.b.w, nd.c.x, nd.c.y, nd.c.z, nd.c.w);
+            bool left_first = ld <= rd;
+            bool push_l = ld < best.t, push_r = rd < best.t;
+            uint32_t near_ref = left_first ? nd.left : nd.right;
+            uint32_t far_ref = left_first ? nd.right : nd.left;
+            bool push_near = left_first ? push_l : push_r;
+            bool push_far = left_first ? push_r : push_l;
+            if (push_far) { stack[sp * LP_BLOCK + tid] = far_ref; sp++; }
+            if (push_near) { cur = near_ref; }
+            else
+            {
+                if (sp == sp_base) break;
+                sp--;
+                cur = stack[sp * LP_BLOCK + tid];
+            }
         }
     }
     return replaced;
@@ -554,15 +448,15 @@ LP_DEV bool blas_closest(const Geo &geo, uint32_t *stack, uint32_t sp_base, uint
 //
 // The reference nests the BLAS loop inside the TLAS loop; compiled as written, lanes that are between
 // instances idle while their neighbours finish a BLAS.  Here TLAS and BLAS internal nodes share one
-// code path (same 128-byte node format, only the ray and the node array differ by level), and the
+// code path (same 64-byte node format, only the ray and the node array differ by level), and the
 // loop is organised "while-while": every lane first descends through internal nodes of either level
 // until it holds a leaf, then the wave handles leaves (instance entry / triangles) together.
 // Visiting order per lane is unchanged, so results are identical to the nested form.
 template <typename Geo>
 LP_DEV Closest scene_closest(const Geo &geo, const SceneDev &sc, uint32_t *stack, f3 o, f3 d, float eps)
 {
-    constexpr uint32_t REF_DONE = 0xFFFFFFFFu;   // not a valid leaf reference (payloads are < 2^30)
-    LdsStack stk; stk.base = stack + threadIdx.x;
+    const uint32_t tid = threadIdx.x;
+    constexpr uint32_t REF_DONE = 0xFFFFFFFFu;   // not a valid leaf reference (leaf payloads are < 2^31 - 1)
     Closest best;
     best.t = LP_F32_MAX; best.u = 0.0f; best.v = 0.0f; best.tri = 0u; best.inst = 0xFFFFFFFFu;
     if (sc.num_instances == 0) return best;
@@ -576,12 +470,10 @@ LP_DEV Closest scene_closest(const Geo &geo, const SceneDev &sc, uint32_t *stack
 
     // pop the next reference; leaving an exhausted BLAS restores the world ray and keeps popping the TLAS part
     auto pop = [&]() {
-        if (blas_base != 0xFFFFFFFFu)
-        {
-            if (q_pop(geo, stk, sp, blas_base, cur, best.t)) return;
-            blas_base = 0xFFFFFFFFu; co = o; cd = d; cinv = inv_d;
-        }
-        if (!q_pop(geo, stk, sp, 0u, cur, best.t)) cur = REF_DONE;
+        if (sp == blas_base) { blas_base = 0xFFFFFFFFu; co = o; cd = d; cinv = inv_d; }
+        if (sp == 0) { cur = REF_DONE; return; }
+        sp--;
+        cur = stack[sp * LP_BLOCK + tid];
     };
 
     for (;;)
@@ -589,8 +481,17 @@ LP_DEV Closest scene_closest(const Geo &geo, const SceneDev &sc, uint32_t *stack
         // ---- phase 1: internal nodes of either level ----
         while (!(cur & REF_LEAF))
         {
-            const QRegs q = geo.qnode(blas_base != 0xFFFFFFFFu, cur);
-            if (!q_visit(geo, q, stk, sp, cur, best.t, co, cinv)) pop();
+            const NodeRegs nd = geo.node(blas_base != 0xFFFFFFFFu, cur);
+            float ld = slab_dst(co, cinv, nd.a.x, nd.a.y, nd.a.z, nd.a.w, nd.b.x, nd.b.y);
+            float rd = slab_dst(co, cinv, nd.b.z, nd.b.w, nd.c.x, nd.c.y, nd.c.z, nd.c.w);
+            bool left_first = ld <= rd;
+            bool push_l = ld < best.t, push_r = rd < best.t;
+            uint32_t near_ref = left_first ? nd.left : nd.right;
+            uint32_t far_ref = left_first ? nd.right : nd.left;
+            bool push_near = left_first ? push_l : push_r;
+            bool push_far = left_first ? push_r : push_l;
+            if (push_far) { stack[sp * LP_BLOCK + tid] = far_ref; sp++; }
+            if (push_near) cur = near_ref; else pop();
         }
         if (cur == REF_DONE) break;
 
@@ -656,6 +557,7 @@ LP_DEV float4 lerp_texels(float4 p, float4 q, float f)
     return make_float4(p.x * g + q.x * f, p.y * g + q.y * f, p.z * g + q.z * f, p.w * g + q.w * f);
 }
 
+template <bool CLAMP_V = false>   // CLAMP_V: experiment only (tools/env_residual.py), the reference's sampler repeats on both axes
 LP_FN float4 sample_texture(const SceneDev &sc, uint32_t tex_idx, float u, float v)
 {
     const TextureDev t = sc.textures[tex_idx];
@@ -671,6 +573,7 @@ LP_FN float4 sample_texture(const SceneDev &sc, uint32_t tex_idx, float u, float
     if ((w & (w - 1)) == 0) xa = x0 & (w - 1); else xa = ((x0 % w) + w) % w;
     if ((h & (h - 1)) == 0) ya = y0 & (h - 1); else ya = ((y0 % h) + h) % h;
     int xb = xa + 1 == w ? 0 : xa + 1, yb = ya + 1 == h ? 0 : ya + 1;
+    if (CLAMP_V) { ya = y0 < 0 ? 0 : (y0 > h - 1 ? h - 1 : y0); yb = y0 + 1 < 0 ? 0 : (y0 + 1 > h - 1 ? h - 1 : y0 + 1); }
     float4 top = lerp_texels(fetch_texel(sc, t, xa, ya), fetch_texel(sc, t, xb, ya), fx);
     float4 bot = lerp_texels(fetch_texel(sc, t, xa, yb), fetch_texel(sc, t, xb, yb), fx);
     return lerp_texels(top, bot, fy);
@@ -927,7 +830,11 @@ LP_FN f3 environment_radiance(const SceneDev &sc, f3 dir)
         f3 e = mk3(env.emission[0], env.emission[1], env.emission[2]);
         if (env.emission_tex_idx != LUPIN_SENTINEL_IDX)
         {
+#ifdef LP_EXPERIMENT_ENV_V_CLAMP
+            float4 t = sample_texture<true>(sc, env.emission_tex_idx, u, v);
+#else
             float4 t = sample_texture(sc, env.emission_tex_idx, u, v);
+#endif
             e = mul(e, mk3(t.x, t.y, t.z));
         }
         total = add(total, e);

@@ -29,7 +29,7 @@ static int fail(int code, const std::string &msg) { g_last_error = msg; return c
 #define HIP_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return fail(LUPIN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } while (0)
 
 #define LP_MAX_LANES 4
-#define LP_WORK_WORDS 24   // 3 tracing modes (closest hit | shadow rays | light-pdf marching) x {nodes, triangles, instances, node fetches}
+#define LP_WORK_WORDS 24   // 3 tracing modes (closest hit | shadow rays | light-pdf marching) x {nodes, triangles, instances, -, node steps, triangle steps, refills, rounds}
 // "Lanes" (stream + path buffers + counters) let consecutive pathtrace_scene calls overlap: the wavefront of
 // frame k+1 starts while the thin tail of frame k is still draining.  Frames only meet at k_resolve (frame k+1 blends
 // with frame k's output), which waits on the previous call's completion event.
@@ -40,7 +40,7 @@ struct Lane
     uint64_t capacity = 0;          // slots the path buffers hold
     uint32_t counts_capacity = 0;
     unsigned long long *stat_counters = nullptr;   // per shard: [2s] path bounces, [2s+1] paths
-    uint32_t *stack_overflow = nullptr;            // deep tail of the persistent tracer's traversal stacks (SplitStack)
+    uint32_t *stack_overflow = nullptr;            // deep tail of the persistent tracer's traversal stacks (RingStack)
     uint64_t overflow_capacity = 0;                // words
     unsigned long long *work_counters = nullptr;   // [3 * mode + {nodes, triangles, instances}] of the COUNT kernels (stats mode 2)
     hipEvent_t done = nullptr;      // recorded after the last kernel of the lane's latest call
@@ -82,7 +82,7 @@ struct LupinContext
     bool use_graph = false;                 // LUPIN_GRAPH=1: replay the lane-private wavefront as a HIP graph (opt-in)
     bool persistent_shadow = true;          // LUPIN_SHADOW=simple: MIS / Direct shadow rays stay in k_shadow even on large scenes
     uint32_t node_steps = 4;               // LUPIN_NODE_STEPS: node visits per scheduling round of k_extend_persistent
-    uint32_t persist_lds_words = 32;       // LUPIN_STACK_LDS_WORDS (32 | 64 | 128): traversal-stack ring of the persistent tracer, words per lane in LDS
+    uint32_t persist_lds_words = 16;       // LUPIN_STACK_LDS_WORDS (8 | 16 | 32 | 64): traversal-stack ring of the persistent tracer, words per lane in LDS
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_extend, ev_shade, ev_total;
     std::vector<hipEvent_t> ev_pool;
     uint64_t extend_launches = 0;
@@ -106,91 +106,14 @@ struct LupinScene
     LupinContext *ctx;
     SceneDev dev{};
     std::vector<void *> allocations;
-    uint32_t stack_entries = 1;                     // worst-case traversal-stack words of a closest-hit query (TLAS + deepest BLAS)
-    uint32_t light_stack_entries = 1;               // ... of light-pdf marching (the BLAS of one emissive instance)
+    uint32_t stack_entries = 1;                     // worst-case traversal-stack words of a closest-hit query (TLAS depth + deepest BLAS + 1)
+    uint32_t light_stack_entries = 1;               // ... of light-pdf marching (the deepest BLAS of an emissive instance + 1)
     uint32_t persistent_blocks[4] = {0, 0, 0, 0};   // grid of k_extend_persistent per integrator (lazy)
     uint64_t id = 0;                                // unique per created scene (graph cache key)
     bool all_opaque = false;                        // no instance can have opacity != 1: k_extend<.., OPAQUE> drops the alpha test
     bool simple_matte = false;                      // only untextured matte materials, no vertex colours, no environments: k_shade<.., SIMPLE>
     bool has_sw_bvh = false;
     bool envs_empty = true, lights_empty = true, instances_empty = true;
-};
-
-// ---- binary hierarchy -> QNodes (lupin_device.hpp) ----
-// `T` gives access to one binary tree: is_leaf(n), leaf_ref(n), leaf_words(n) (stack words a traversal below that leaf can
-// need: 0 for triangles, the mesh's figure for an instance), child(n, side), lo(n) / hi(n).
-// Returns the reference of node n and the worst-case number of stack words a traversal of its subtree can hold at once
-// (relative to the height at entry): at a node the far side is parked (4 words for a PAIR, 1 for a SINGLE) while the near
-// side is descended; a PAIR side parks one more word, the far grandchild.
-struct QOut { uint32_t ref, words; };
-template <typename T>
-static QOut build_qnodes(const T &t, uint32_t n, std::vector<QNode> &out, uint32_t base, bool use_pairs)
-{
-    if (t.is_leaf(n)) return {t.leaf_ref(n), t.leaf_words(n)};
-    const uint32_t idx = (uint32_t)out.size();
-    out.emplace_back();
-    float box[4][6];
-    uint32_t refs[4] = {REF_NONE, REF_NONE, REF_NONE, REF_NONE};   // slot 1 / 3 left at REF_NONE marks the side SINGLE
-    memset(box, 0, sizeof(box));
-    uint32_t cost[2], sub[2];
-    for (uint32_t side = 0; side < 2; side++)
-    {
-        const uint32_t c = t.child(n, side);
-        bool pair = use_pairs && !t.is_leaf(c);
-        uint32_t g0 = 0, g1 = 0;
-        if (pair)
-        {
-            g0 = t.child(c, 0); g1 = t.child(c, 1);
-            for (int k = 0; k < 3 && pair; k++)   // the child's box must be the exact union of its children's
-                pair = t.lo(c)[k] == std::min(t.lo(g0)[k], t.lo(g1)[k]) && t.hi(c)[k] == std::max(t.hi(g0)[k], t.hi(g1)[k]);
-        }
-        if (pair)
-        {
-            for (int k = 0; k < 3; k++)
-            {
-                box[2 * side][k] = t.lo(g0)[k]; box[2 * side][3 + k] = t.hi(g0)[k];
-                box[2 * side + 1][k] = t.lo(g1)[k]; box[2 * side + 1][3 + k] = t.hi(g1)[k];
-            }
-            const QOut a = build_qnodes(t, g0, out, base, use_pairs), b = build_qnodes(t, g1, out, base, use_pairs);
-            refs[2 * side] = a.ref; refs[2 * side + 1] = b.ref;
-            cost[side] = 4; sub[side] = 1 + std::max(a.words, b.words);
-        }
-        else
-        {
-            for (int k = 0; k < 3; k++) { box[2 * side][k] = t.lo(c)[k]; box[2 * side][3 + k] = t.hi(c)[k]; }
-            const QOut a = build_qnodes(t, c, out, base, use_pairs);
-            refs[2 * side] = a.ref;
-            cost[side] = 1; sub[side] = a.words;
-        }
-    }
-    QNode q;
-    const float *f = &box[0][0];
-    for (int k = 0; k < 6; k++) q.w[k] = make_float4(f[4 * k + 0], f[4 * k + 1], f[4 * k + 2], f[4 * k + 3]);
-    q.w[6] = make_float4(host_u2f(refs[0]), host_u2f(refs[1]), host_u2f(refs[2]), host_u2f(refs[3]));
-    q.w[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    out[idx] = q;
-    return {idx - base, std::max(cost[1] + sub[0], cost[0] + sub[1])};
-}
-
-struct BlasTree
-{
-    const LupinBvhNode *nodes; uint32_t tri_offset;
-    bool is_leaf(uint32_t n) const { return nodes[n].tri_count > 0; }
-    uint32_t leaf_ref(uint32_t n) const { return REF_LEAF | (tri_offset + nodes[n].tri_begin_or_first_child); }
-    uint32_t leaf_words(uint32_t) const { return 0; }
-    uint32_t child(uint32_t n, uint32_t side) const { return nodes[n].tri_begin_or_first_child + side; }
-    const float *lo(uint32_t n) const { return nodes[n].aabb_min; }
-    const float *hi(uint32_t n) const { return nodes[n].aabb_max; }
-};
-struct TlasTree
-{
-    const LupinTlasNode *nodes; const LupinInstance *instances; const uint32_t *mesh_words;
-    bool is_leaf(uint32_t n) const { return nodes[n].left == 0; }
-    uint32_t leaf_ref(uint32_t n) const { return REF_LEAF | nodes[n].instance_idx; }
-    uint32_t leaf_words(uint32_t n) const { return mesh_words[instances[nodes[n].instance_idx].mesh_idx]; }
-    uint32_t child(uint32_t n, uint32_t side) const { return side == 0 ? nodes[n].left : nodes[n].right; }
-    const float *lo(uint32_t n) const { return nodes[n].aabb_min; }
-    const float *hi(uint32_t n) const { return nodes[n].aabb_max; }
 };
 
 template <typename T>
@@ -276,7 +199,7 @@ static uint32_t blas_depth(const LupinBvhNode *nodes, uint32_t count)
 
 // Dynamic LDS of the stage kernels: [traversal stack words x LP_BLOCK][geometry blob, if staged].  Each kernel sizes the
 // stack for the traversals it runs: closest-hit kernels the scene's worst case, k_shade the light-pdf marching of one
-// BLAS, the persistent tracer a fixed number of words (the deep tail goes to global memory).
+// BLAS, the persistent tracer a small ring (the deep tail goes to global memory, RingStack).
 struct StackPlan
 {
     uint32_t full_words = 1, light_words = 1, persist_words = 1, blob_bytes = 0;
@@ -514,7 +437,7 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
     const char *ns = getenv("LUPIN_NODE_STEPS");
     if (ns) ctx->node_steps = (uint32_t)std::min(16, std::max(1, atoi(ns)));
     const char *slw = getenv("LUPIN_STACK_LDS_WORDS");
-    if (slw) { const int v = atoi(slw); ctx->persist_lds_words = v >= 128 ? 128u : (v >= 64 ? 64u : 32u); }
+    if (slw) { const int v = atoi(slw); ctx->persist_lds_words = v >= 64 ? 64u : (v >= 32 ? 32u : (v >= 16 ? 16u : 8u)); }
     const char *rm = getenv("LUPIN_REFILL_MIN");
     if (rm) ctx->refill_min = (uint32_t)std::min(64, std::max(1, atoi(rm)));
     *out_ctx = ctx;
@@ -655,15 +578,14 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
         for (uint32_t v = 0; v < s.verts_color_array[b].num_verts; v++) { const float *p = s.verts_color_array[b].data + (size_t)v * 4; colors.push_back(make_float4(p[0], p[1], p[2], p[3])); }
     }
 
-    // ---- meshes: triangles in leaf order, BLAS as 128-byte two-level nodes ----
+    // ---- meshes: triangles in leaf order, BLAS as 64-byte child-pair nodes ----
     std::vector<TriVerts> tris;
     std::vector<uint32_t> tri_indices;
-    std::vector<QNode> blas;
+    std::vector<WideNode> blas;
     std::vector<MeshDev> meshes(s.num_meshes);
     std::vector<uint32_t> mesh_root(s.num_meshes);
-    std::vector<uint32_t> mesh_words(s.num_meshes, 0u);   // worst-case traversal-stack words inside the mesh's BLAS
-    const char *qenv = getenv("LUPIN_QNODES");
-    const bool use_pairs = !(qenv && strcmp(qenv, "0") == 0);   // LUPIN_QNODES=0: every side SINGLE = one binary level per fetch (A/B runs)
+    uint32_t max_blas_depth = 0;
+    std::vector<uint32_t> mesh_depth(s.num_meshes, 0u);
     for (uint32_t mi = 0; mi < s.num_meshes; mi++)
     {
         const LupinMeshDesc &m = s.meshes[mi];
@@ -710,74 +632,101 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
             tri_indices.push_back(0); tri_indices.push_back(0); tri_indices.push_back(0);
             continue;
         }
+        // node index -> child reference
+        std::vector<uint32_t> ref(m.num_bvh_nodes);
+        uint32_t wide_base = (uint32_t)blas.size(), wide_count = 0;
         for (uint32_t n = 0; n < m.num_bvh_nodes; n++)
         {
             const LupinBvhNode &nd = m.bvh_nodes[n];
             if (nd.tri_count > 0)
             {
                 if ((uint64_t)nd.tri_begin_or_first_child + nd.tri_count > ntris) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "BLAS leaf range out of bounds"); }
+                ref[n] = REF_LEAF | (md.tri_offset + nd.tri_begin_or_first_child);
                 uint32_t last = md.tri_offset + nd.tri_begin_or_first_child + nd.tri_count - 1;
                 tris[last].v0.w = host_u2f(LEAF_END_BITS);
             }
-            else if ((uint64_t)nd.tri_begin_or_first_child + 1 >= m.num_bvh_nodes) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "BLAS child index out of bounds"); }
+            else
+            {
+                if ((uint64_t)nd.tri_begin_or_first_child + 1 >= m.num_bvh_nodes) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "BLAS child index out of bounds"); }
+                ref[n] = wide_base + wide_count++;
+            }
         }
-        if (blas_depth(m.bvh_nodes, m.num_bvh_nodes) == 0xFFFFFFFFu) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "BLAS is not a tree"); }
-        mesh_root[mi] = 0u;   // converted below
+        blas.resize(wide_base + wide_count);
+        for (uint32_t n = 0; n < m.num_bvh_nodes; n++)
+        {
+            const LupinBvhNode &nd = m.bvh_nodes[n];
+            if (nd.tri_count > 0) continue;
+            const LupinBvhNode &l = m.bvh_nodes[nd.tri_begin_or_first_child];
+            const LupinBvhNode &r = m.bvh_nodes[nd.tri_begin_or_first_child + 1];
+            WideNode w;
+            w.a = make_float4(l.aabb_min[0], l.aabb_min[1], l.aabb_min[2], l.aabb_max[0]);
+            w.b = make_float4(l.aabb_max[1], l.aabb_max[2], r.aabb_min[0], r.aabb_min[1]);
+            w.c = make_float4(r.aabb_min[2], r.aabb_max[0], r.aabb_max[1], r.aabb_max[2]);
+            w.d = make_uint4(ref[nd.tri_begin_or_first_child], ref[nd.tri_begin_or_first_child + 1], 0u, 0u);
+            blas[ref[n]] = w;
+        }
+        mesh_root[mi] = ref[0];
+        const uint32_t bd = blas_depth(m.bvh_nodes, m.num_bvh_nodes);
+        if (bd == 0xFFFFFFFFu) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "BLAS is not a tree"); }
+        max_blas_depth = std::max(max_blas_depth, bd);
+        mesh_depth[mi] = bd;
     }
 
     // ---- TLAS ----
-    std::vector<QNode> tlas;
+    std::vector<WideNode> tlas;
     uint32_t tlas_root = REF_LEAF;
-    uint32_t stack_words = 1;
+    uint32_t tlas_depth = 0;
     if (s.num_tlas_nodes > 0)
     {
+        std::vector<uint32_t> ref(s.num_tlas_nodes);
+        uint32_t wide_count = 0;
         for (uint32_t n = 0; n < s.num_tlas_nodes; n++)
         {
             const LupinTlasNode &nd = s.tlas_nodes[n];
-            if (nd.left == 0) { if (nd.instance_idx >= s.num_instances) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "TLAS leaf instance out of range"); } }
-            else if (nd.left >= s.num_tlas_nodes || nd.right >= s.num_tlas_nodes) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "TLAS child out of range"); }
+            if (nd.left == 0)
+            {
+                if (nd.instance_idx >= s.num_instances) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "TLAS leaf instance out of range"); }
+                ref[n] = REF_LEAF | nd.instance_idx;
+            }
+            else
+            {
+                if (nd.left >= s.num_tlas_nodes || nd.right >= s.num_tlas_nodes) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "TLAS child out of range"); }
+                ref[n] = wide_count++;
+            }
         }
-        // bounded walk from the root: a malformed cyclic TLAS is rejected
-        std::vector<uint32_t> st;
-        st.push_back(0u);
+        tlas.resize(wide_count);
+        for (uint32_t n = 0; n < s.num_tlas_nodes; n++)
+        {
+            const LupinTlasNode &nd = s.tlas_nodes[n];
+            if (nd.left == 0) continue;
+            const LupinTlasNode &l = s.tlas_nodes[nd.left];
+            const LupinTlasNode &r = s.tlas_nodes[nd.right];
+            WideNode w;
+            w.a = make_float4(l.aabb_min[0], l.aabb_min[1], l.aabb_min[2], l.aabb_max[0]);
+            w.b = make_float4(l.aabb_max[1], l.aabb_max[2], r.aabb_min[0], r.aabb_min[1]);
+            w.c = make_float4(r.aabb_min[2], r.aabb_max[0], r.aabb_max[1], r.aabb_max[2]);
+            w.d = make_uint4(ref[nd.left], ref[nd.right], 0u, 0u);
+            tlas[ref[n]] = w;
+        }
+        tlas_root = ref[0];
+        // depth from the root (bounded walk: a malformed cyclic TLAS is rejected)
+        std::vector<std::pair<uint32_t, uint32_t>> st;
+        st.push_back({0u, 0u});
         uint64_t visited = 0;
         while (!st.empty())
         {
-            const uint32_t n = st.back();
+            auto [n, d] = st.back();
             st.pop_back();
             if (++visited > (uint64_t)s.num_tlas_nodes * 2 + 2) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "TLAS is not a tree"); }
-            if (s.tlas_nodes[n].left != 0) { st.push_back(s.tlas_nodes[n].left); st.push_back(s.tlas_nodes[n].right); }
+            if (s.tlas_nodes[n].left != 0)
+            {
+                tlas_depth = std::max(tlas_depth, d + 1);
+                st.push_back({s.tlas_nodes[n].left, d + 1});
+                st.push_back({s.tlas_nodes[n].right, d + 1});
+            }
         }
     }
-    // both levels -> QNodes; if pairing makes the worst-case stack too large for the kernels that keep it all in LDS, fall
-    // back to one binary level per node (every side SINGLE: the worst case is then the hierarchy's depth)
-    auto convert = [&](bool pairs) {
-        blas.clear(); tlas.clear();
-        for (uint32_t mi = 0; mi < s.num_meshes; mi++)
-        {
-            const LupinMeshDesc &m = s.meshes[mi];
-            if (m.num_indices / 3 == 0 || m.num_bvh_nodes == 0) continue;   // degenerate mesh: its leaf reference was set above
-            BlasTree bt; bt.nodes = m.bvh_nodes; bt.tri_offset = meshes[mi].tri_offset;
-            const QOut root = build_qnodes(bt, 0u, blas, 0u, pairs);
-            mesh_root[mi] = root.ref;
-            mesh_words[mi] = root.words;
-        }
-        stack_words = 1;
-        if (s.num_tlas_nodes > 0)
-        {
-            TlasTree tt; tt.nodes = s.tlas_nodes; tt.instances = s.instances; tt.mesh_words = mesh_words.data();
-            const QOut root = build_qnodes(tt, 0u, tlas, 0u, pairs);
-            tlas_root = root.ref;
-            stack_words = root.words + 1;
-        }
-        for (uint32_t w : mesh_words) stack_words = std::max(stack_words, w + 1);   // light-pdf marching walks single BLASes
-        stack_words += 4;   // q_visit writes up to four words above the stack top before deciding to keep them
-    };
-    convert(use_pairs);
-    if (use_pairs && stack_words > 128u) convert(false);
-    if (tris.size() >= REF_DEFERRED || blas.size() >= REF_DEFERRED || tlas.size() >= REF_DEFERRED || s.num_instances >= REF_DEFERRED)
-    { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "scene too large: child references hold 30 bits"); }
-    sc->stack_entries = stack_words;
+    sc->stack_entries = tlas_depth + max_blas_depth + 1;
 
     // ---- instances ----
     std::vector<InstanceDev> instances(s.num_instances);
@@ -841,7 +790,7 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
     // stored world->local rows, in double, radius padded): lights_pdf skips lights whose sphere the ray cannot reach.
     // A skipped light contributes exactly +0.0f in the reference's sum, so results do not change.
     uint32_t light_words = 1;
-    for (uint32_t i = 0; i < s.num_lights; i++) light_words = std::max(light_words, mesh_words[s.instances[s.lights[i].instance_idx].mesh_idx] + 5);
+    for (uint32_t i = 0; i < s.num_lights; i++) light_words = std::max(light_words, mesh_depth[s.instances[s.lights[i].instance_idx].mesh_idx] + 1);
     sc->light_stack_entries = light_words;
     std::vector<float4> light_bounds(s.num_lights);
     for (uint32_t i = 0; i < s.num_lights; i++)
@@ -884,16 +833,16 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
     std::vector<float4> geo_blob;
     uint32_t off_blas = 0, off_tris = 0, off_inst = 0;
     {
-        const size_t bytes = tlas.size() * 128 + blas.size() * 128 + tris.size() * 48 + instances.size() * 64;
+        const size_t bytes = tlas.size() * 64 + blas.size() * 64 + tris.size() * 48 + instances.size() * 64;
         if (bytes > 0 && bytes <= LP_GEO_LDS_LIMIT)
         {
             auto append = [&](const void *p, size_t nbytes) {
                 const float4 *f = reinterpret_cast<const float4 *>(p);
                 geo_blob.insert(geo_blob.end(), f, f + nbytes / 16);
             };
-            append(tlas.data(), tlas.size() * 128);
+            append(tlas.data(), tlas.size() * 64);
             off_blas = (uint32_t)geo_blob.size();
-            append(blas.data(), blas.size() * 128);
+            append(blas.data(), blas.size() * 64);
             off_tris = (uint32_t)geo_blob.size();
             append(tris.data(), tris.size() * 48);
             off_inst = (uint32_t)geo_blob.size();
@@ -1203,8 +1152,8 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
     plan.blob_bytes = lds_geo ? scene->dev.geo_blob_words * 16u : 0u;
     const bool persistent_path = use_persistent(ctx, lds_geo);
     const size_t lds = persistent_path ? plan.lds(plan.persist_words) : plan.lds(plan.full_words);   // the closest-hit kernel's
-    if (plan.lds(persistent_path && (pathtrace_type == LUPIN_PATHTRACE_STANDARD || pathtrace_type == LUPIN_PATHTRACE_NAIVE || ctx->persistent_shadow)
-                     ? std::max(plan.persist_words, plan.light_words) : plan.full_words) > 160 * 1024)
+    const bool all_traced_persistently = persistent_path && (pathtrace_type == LUPIN_PATHTRACE_STANDARD || pathtrace_type == LUPIN_PATHTRACE_NAIVE || ctx->persistent_shadow);
+    if (plan.lds(all_traced_persistently ? std::max(plan.persist_words, plan.light_words) : plan.full_words) > 160 * 1024)
         return fail(LUPIN_ERR_INVALID_ARGUMENT, "BVH too deep for the LDS traversal stack");
 
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -1213,8 +1162,8 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
     const uint32_t pblocks = persistent_grid(ctx, scene, pathtrace_type, lds_geo, lds);
     if (pblocks)
     {
-        // deep tail of the persistent tracer's stacks: (worst case - words kept in LDS) per resident thread
-        const uint64_t need = (uint64_t)(plan.full_words + 16u) * pblocks * LP_BLOCK;
+        // deep tail of the persistent tracer's stacks: the scene's worst case per resident thread (RingStack indexes it by absolute depth)
+        const uint64_t need = (uint64_t)(plan.full_words + 8u) * pblocks * LP_BLOCK;
         if (need > ln->overflow_capacity)
         {
             HIP_TRY(hipStreamSynchronize(st));
@@ -1363,7 +1312,7 @@ int lupin_hip_stats_get(LupinContext *ctx, LupinStats *out)
     {
         unsigned long long w[LP_WORK_WORDS];
         HIP_TRY(hipMemcpy(w, ctx->lanes[l].work_counters, sizeof(w), hipMemcpyDeviceToHost));
-        for (int m = 0; m < 3; m++) { out->node_visits[m] += w[8 * m + 0]; out->tri_tests[m] += w[8 * m + 1]; out->instance_entries[m] += w[8 * m + 2]; out->node_fetches[m] += w[8 * m + 3]; for (int k = 0; k < 4; k++) out->sched[m][k] += w[8 * m + 4 + k]; }
+        for (int m = 0; m < 3; m++) { out->node_visits[m] += w[8 * m + 0]; out->tri_tests[m] += w[8 * m + 1]; out->instance_entries[m] += w[8 * m + 2]; for (int k = 0; k < 4; k++) out->sched[m][k] += w[8 * m + 4 + k]; }
     }
     out->extend_launches = ctx->extend_launches;
     auto sum = [](const std::vector<std::pair<hipEvent_t, hipEvent_t>> &v) {

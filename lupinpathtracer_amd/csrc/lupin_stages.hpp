@@ -259,7 +259,8 @@ __device__ __forceinline__ void trace_alpha(const Geo &geo, const SceneDev &sc, 
 }
 
 // Work counters (bench.py's roofline numerator, lupin_hip_stats_reset(ctx, 2)): the COUNT instantiations of the tracing
-// kernels wrap their geometry accessor in GeoTally and add the wave's totals to work[4 * mode + {0 nodes, 1 triangles, 2 instances, 3 node fetches}].
+// kernels wrap their geometry accessor in GeoTally and add the wave's totals to work[8 * mode + {0 nodes, 1 triangles, 2 instances,
+// 4 wave-level node steps, 5 triangle steps, 6 refills, 7 scheduling rounds}].
 // All 64 lanes must be active when this is called.
 __device__ __forceinline__ void tally_flush(const uint32_t (&tally)[8], unsigned long long *work)
 {
@@ -346,7 +347,7 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
     const auto base_geo = make_geo<LDSGEO>(sc, lds_stack, stack_words);
     uint32_t tally[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     const auto geo = with_tally<COUNT>(base_geo, tally);
-    RingStack stk;   // stack_words / LP_BLOCK = ring size, a power of two >= 32 (host)
+    RingStack stk;   // stack_words / LP_BLOCK = ring size, a power of two (host)
     stk.lds = lds_stack + threadIdx.x; stk.mask = stack_words / LP_BLOCK - 1u; stk.floor = 0u;
     stk.threads = gridDim.x * LP_BLOCK; stk.overflow = stack_overflow + (size_t)blockIdx.x * LP_BLOCK + threadIdx.x;
     static_assert(LP_SHARDS <= LP_BLOCK && 256 % LP_SHARDS == 0, "block 0 books one shard per thread; 64-block grids hold whole waves per shard");
@@ -388,12 +389,9 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
         best.t = LP_F32_MAX; best.u = 0.0f; best.v = 0.0f; best.tri = 0u; best.inst = HIT_MISS;
     };
     auto pop = [&]() {
-        if (blas_base != 0xFFFFFFFFu)
-        {
-            if (q_pop(geo, stk, sp, blas_base, cur, best.t)) return;
-            blas_base = 0xFFFFFFFFu; co = o; cd = d; cinv = inv_d;   // the BLAS is exhausted: back to the world ray
-        }
-        if (!q_pop(geo, stk, sp, 0u, cur, best.t)) cur = REF_DONE;
+        if (sp == blas_base) { blas_base = 0xFFFFFFFFu; co = o; cd = d; cinv = inv_d; }
+        if (sp == 0) { cur = REF_DONE; return; }
+        cur = stk.pop(sp);
     };
 
     // Phase scheduling: a lane is at an internal node (N), a TLAS leaf = instance entry (I), a triangle of a BLAS leaf (T),
@@ -477,8 +475,17 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
                 if (COUNT && lane == 0u) tally[4]++;   // node steps of this wave
                 if (n)
                 {
-                    const QRegs q = geo.qnode(blas_base != 0xFFFFFFFFu, cur);
-                    if (!q_visit(geo, q, stk, sp, cur, best.t, co, cinv)) pop();
+                    const NodeRegs nd = geo.node(blas_base != 0xFFFFFFFFu, cur);
+                    float ld = slab_dst(co, cinv, nd.a.x, nd.a.y, nd.a.z, nd.a.w, nd.b.x, nd.b.y);
+                    float rd = slab_dst(co, cinv, nd.b.z, nd.b.w, nd.c.x, nd.c.y, nd.c.z, nd.c.w);
+                    bool left_first = ld <= rd;
+                    bool push_l = ld < best.t, push_r = rd < best.t;
+                    uint32_t near_ref = left_first ? nd.left : nd.right;
+                    uint32_t far_ref = left_first ? nd.right : nd.left;
+                    bool push_near = left_first ? push_l : push_r;
+                    bool push_far = left_first ? push_r : push_l;
+                    if (push_far) stk.push(sp, far_ref);
+                    if (push_near) cur = near_ref; else pop();
                 }
             }
         }

@@ -62,3 +62,16 @@ def gpu_accumulate(ctx, scene, cam, width, height, frames, spp, max_bounces=8, p
         out.flip()
     out.flip()
     return out.front().download()
+
+
+def furnace_variant(ctx, mat_type, **fields):
+    """The reference's white-furnace scene (test_scenes/furnace1: constant environment 0.5, one sphere) with the sphere's
+    material replaced: a closed-form energy test for materials no reference scene uses (subsurface, gltfpbr)."""
+    from lupinpathtracer_amd import api, loader
+    path = os.path.join(SCENES, "furnace1", "furnace1.json")
+    scene_cpu, textures, envs_info, cams = loader.load_scene_cpu_yoctogl_v24(path, [SHARED])
+    m = scene_cpu.materials[0]
+    m["mat_type"] = int(mat_type)
+    for k, v in fields.items():
+        m[k] = v
+    return api.build_accel_structures_and_upload(ctx, scene_cpu, textures, envs_info, True), cams
