@@ -103,7 +103,7 @@ struct SceneDev
     const uint8_t *texels;
     const LupinEnvironment *environments;
     const LupinLight *lights;
-    const float4 *light_bounds;          // per light: conservative world-space sphere (xyz centre, w padded radius)
+    const float4 *light_bounds;          // per light: conservative world-space sphere (xyz centre, w = padded radius squared)
     const AliasRange *alias_ranges;      // per light
     const AliasRange *env_alias_ranges;  // per environment
     const LupinAliasBin *alias_bins;     // pool
@@ -247,6 +247,11 @@ typedef __attribute__((address_space(3))) const v4f *lds_v4p;
 constexpr uint32_t LP_GEO_LDS_LIMIT = 24 * 1024;
 
 struct NodeRegs { float4 a, b, c; uint32_t left, right; };
+// One 64-byte record of any of the three kinds a traversal step needs (0 = WideNode, 1 = TriVerts + 16 bytes of whatever
+// follows, 2 = InstanceDev), fetched by ONE set of four 16-byte loads whatever the lane is about to do: the persistent
+// tracer lets every lane take its own next step in every round, and the loads of all three kinds fly together.
+struct Fetch64 { float4 w0, w1, w2, w3; };
+LP_DEV NodeRegs as_node(const Fetch64 &f) { NodeRegs r; r.a = f.w0; r.b = f.w1; r.c = f.w2; r.left = __float_as_uint(f.w3.x); r.right = __float_as_uint(f.w3.y); return r; }
 
 struct GeoGlobal
 {
@@ -258,6 +263,13 @@ struct GeoGlobal
         const WideNode nd = (in_blas ? blas : tlas)[i];
         NodeRegs r; r.a = nd.a; r.b = nd.b; r.c = nd.c; r.left = nd.d.x; r.right = nd.d.y;
         return r;
+    }
+    LP_DEV Fetch64 fetch(uint32_t kind, bool in_blas, uint32_t i) const
+    {
+        const float4 *p = kind == 0u ? reinterpret_cast<const float4 *>((in_blas ? blas : tlas) + i)
+                        : (kind == 1u ? reinterpret_cast<const float4 *>(tris + i) : reinterpret_cast<const float4 *>(instances + i));
+        Fetch64 f; f.w0 = p[0]; f.w1 = p[1]; f.w2 = p[2]; f.w3 = p[3];   // every device array is padded by 64 bytes at upload
+        return f;
     }
     LP_DEV TriVerts tri(uint32_t i) const { return tris[i]; }           // a triangle TEST fetches through tri()
     LP_DEV TriVerts tri_fetch(uint32_t i) const { return tris[i]; }     // shading re-reads vertices through tri_fetch()
@@ -276,6 +288,12 @@ struct GeoLds
         const v4f a = p[0], b = p[1], c = p[2], d = p[3];
         NodeRegs r; r.a = f4(a); r.b = f4(b); r.c = f4(c); r.left = __float_as_uint(d.x); r.right = __float_as_uint(d.y);
         return r;
+    }
+    LP_DEV Fetch64 fetch(uint32_t kind, bool in_blas, uint32_t i) const
+    {
+        lds_v4p p = base + (kind == 0u ? (in_blas ? off_blas : 0u) + i * 4u : (kind == 1u ? off_tris + i * 3u : off_inst + i * 4u));
+        Fetch64 f; f.w0 = f4(p[0]); f.w1 = f4(p[1]); f.w2 = f4(p[2]); f.w3 = f4(p[3]);   // the blob ends with the instances: a triangle's 4th word exists
+        return f;
     }
     LP_DEV TriVerts tri(uint32_t i) const
     {
@@ -305,6 +323,11 @@ struct GeoCounting
     uint32_t *aabb_checks, *tri_checks;   // the calling thread's counters
     static constexpr bool kCounting = true;
     LP_DEV NodeRegs node(bool in_blas, uint32_t i) const { *aabb_checks += 2u; return base.node(in_blas, i); }
+    LP_DEV Fetch64 fetch(uint32_t kind, bool in_blas, uint32_t i) const
+    {
+        if (kind == 0u) *aabb_checks += 2u; else if (kind == 1u) *tri_checks += 1u;
+        return base.fetch(kind, in_blas, i);
+    }
     LP_DEV TriVerts tri(uint32_t i) const { *tri_checks += 1u; return base.tri(i); }
     LP_DEV TriVerts tri_fetch(uint32_t i) const { return base.tri(i); }
     LP_DEV InstanceDev inst(uint32_t i) const { return base.inst(i); }
@@ -320,6 +343,7 @@ struct GeoTally
     uint32_t *tally;   // [0] node visits, [1] triangle tests, [2] instance entries ([3..7]: scheduling diagnostics of the persistent tracer)
     static constexpr bool kCounting = false;   // light culling stays on: the tally is of the work actually done
     LP_DEV NodeRegs node(bool in_blas, uint32_t i) const { tally[0] += 1u; return base.node(in_blas, i); }
+    LP_DEV Fetch64 fetch(uint32_t kind, bool in_blas, uint32_t i) const { tally[kind] += 1u; return base.fetch(kind, in_blas, i); }
     LP_DEV TriVerts tri(uint32_t i) const { tally[1] += 1u; return base.tri(i); }
     LP_DEV TriVerts tri_fetch(uint32_t i) const { return base.tri_fetch(i); }
     LP_DEV InstanceDev inst(uint32_t i) const { tally[2] += 1u; return base.inst(i); }
@@ -1484,28 +1508,38 @@ LP_FN float lights_pdf(const Geo &geo, const SceneDev &sc, uint32_t *stack, f3 p
 {
     float pdf = 0.0f;
     // every emissive instance: march the ray through its BLAS (<= 100 crossings), no occlusion test.
-    // Phase 1 (wave-uniform loop, scalar loads): which lights can this ray reach at all?  Conservative sphere test, the
-    // radius additionally padded by 1e-5 x distance for the rounding of the test itself.  Phase 2: each lane walks its own
+    // Phase 1 (wave-uniform loop, scalar loads): which lights can this ray reach at all?  Conservative sphere test (the
+    // radius is padded at upload, the test's own rounding by an explicit error term).  Phase 2: each lane walks its own
     // candidates in increasing light order, so the sum below has the reference's order and the skipped terms are +0.0f.
     float mesh_pdf = 0.0f;
     const float dd = dot3(incoming, incoming);
+#ifdef LP_EXPERIMENT_SKIP_MESH_LIGHT_PDF   // timing experiment only: how much of k_shade is culling + marching?
+    for (uint32_t base = 0; base < 0u; base += 32u)
+#else
     for (uint32_t base = 0; base < sc.num_lights; base += 32u)
+#endif
     {
         const uint32_t cnt = (sc.num_lights - base) < 32u ? (sc.num_lights - base) : 32u;
         uint32_t mask = 0u;
         for (uint32_t k = 0; k < cnt; k++)
         {
-            const float4 b = sc.light_bounds[base + k];
+            const float4 b = sc.light_bounds[base + k];   // centre, padded radius SQUARED
             const f3 v = mk3(b.x - pos.x, b.y - pos.y, b.z - pos.z);
-            const float R = b.w + 1e-5f * (fabsf(v.x) + fabsf(v.y) + fabsf(v.z));
-            const float vv = dot3(v, v);
-            const f3 cr = cross3(v, incoming);
-            const bool behind = dot3(v, incoming) < 0.0f && eps > 0.0f;   // hits need t >= eps
-            const bool reach = behind ? (vv <= R * R) : (dot3(cr, cr) <= R * R * dd);
+            const float vv = dot3(v, v), vd = dot3(v, incoming);
+            // distance^2 from the centre to the ray's line, times dd:  vv dd - vd^2  (Lagrange).  Its rounding error is below
+            // 1e-6 vv dd, which the right-hand side adds four times over; hits need t >= eps > 0, so a sphere behind the
+            // origin only counts if the origin is inside it.  The comparisons are written so that NaN / inf keep the light.
+            const bool behind = vd < 0.0f && eps > 0.0f;
+            const bool out_of_reach = behind ? (vv > b.w) : (vv * dd - vd * vd > (b.w + 4e-6f * vv) * dd);
+            const bool reach = !out_of_reach;
             // "not provably out of reach": NaN / inf operands keep the light
             // (the debug heat maps count every light's tests, so the counting accessor keeps them all)
-            if (Geo::kCounting || reach || !(vv == vv) || !(R < LP_F32_MAX)) mask |= 1u << k;
+            if (Geo::kCounting || reach) mask |= 1u << k;
         }
+#ifdef LP_EXPERIMENT_SKIP_LIGHT_MARCH   // timing experiment only: culling without the marching
+        mesh_pdf += (float)__builtin_popcount(mask) * 1e-9f;
+        mask = 0u;
+#endif
         while (mask)
         {
         const uint32_t i = base + (uint32_t)__builtin_ctz(mask);

@@ -29,6 +29,7 @@ static int fail(int code, const std::string &msg) { g_last_error = msg; return c
 #define HIP_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return fail(LUPIN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } while (0)
 
 #define LP_MAX_LANES 4
+#define LP_COUNT_PLANES 4   // PathBuffers::counts: the queue counts + one plane of work cursors per persistent-tracer mode
 #define LP_WORK_WORDS 24   // 3 tracing modes (closest hit | shadow rays | light-pdf marching) x {nodes, triangles, instances, -, node steps, triangle steps, refills, rounds}
 // "Lanes" (stream + path buffers + counters) let consecutive pathtrace_scene calls overlap: the wavefront of
 // frame k+1 starts while the thin tail of frame k is still draining.  Frames only meet at k_resolve (frame k+1 blends
@@ -120,7 +121,7 @@ template <typename T>
 static int upload(LupinScene *sc, const std::vector<T> &host, const T **out)
 {
     *out = nullptr;
-    size_t bytes = std::max<size_t>(host.size() * sizeof(T), sizeof(T) > 16 ? sizeof(T) : 16);
+    size_t bytes = std::max<size_t>(host.size() * sizeof(T), sizeof(T) > 16 ? sizeof(T) : 16) + 64;   // + 64: Geo::fetch reads whole 64-byte records
     void *d = nullptr;
     HIP_TRY(hipMalloc(&d, bytes));
     sc->allocations.push_back(d);
@@ -166,8 +167,9 @@ static int ensure_path_buffers(LupinContext *ctx0, Lane *ctx, uint64_t slots, ui
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->pb.counts) hipFree(ctx->pb.counts);
         ctx->pb.counts = nullptr;
-        HIP_TRY(hipMalloc((void **)&ctx->pb.counts, (size_t)(iterations + 2) * LP_SHARDS * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **)&ctx->pb.counts, (size_t)(iterations + 2) * LP_SHARDS * LP_COUNT_PLANES * sizeof(uint32_t)));
         ctx->counts_capacity = iterations + 2;
+        ctx->pb.counts_stride = (iterations + 2) * LP_SHARDS;
         ctx->pb_generation++;
     }
     return LUPIN_OK;
@@ -216,10 +218,13 @@ static uint32_t persistent_grid_t(LupinContext *ctx, const LupinScene *scene, si
     {
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extend_persistent<TYPE, LDSGEO, 0, false>, LP_BLOCK, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-        // With frames in flight the persistent tracer of one frame shares the chip with the shading of another: when five
-        // or more of its blocks fit per CU, three leave that room and the pair finishes sooner (materials1 / environments1
-        // +5 %); deeper scenes fit four at most and are latency-bound, they keep them all (bistro-class -9 % with two).
-        if (ctx->num_lanes > 1 && per_cu > 4) per_cu = 3;
+        // The tracer is latency-bound: throughput grows with the rays in flight (bistro-class, serial kernel time per two 4K
+        // frames: 354 / 297 / 269 ms at 3 / 4 / 5 blocks per CU), but with frames in flight its blocks share the CU with the
+        // shading of another frame: whole-frame throughput is flat from 4 blocks on (226 vs 229 ms per step), and small
+        // scenes whose rays finish quickly prefer to leave room (materials1 / environments1 +5 % with 3).  With the LDS
+        // ring stack five blocks fit for every scene (86 VGPRs); four are used when the scene is traversed from global
+        // memory, three when its geometry is staged in LDS.
+        if (ctx->num_lanes > 1 && per_cu > 4) per_cu = LDSGEO ? 3 : 4;
         if (ctx->blocks_per_cu_override > 0) per_cu = ctx->blocks_per_cu_override;
         cached = std::max(64u, ctx->num_cus * (uint32_t)per_cu / 64u * 64u);
     }
@@ -313,7 +318,7 @@ static hipError_t enqueue_wavefront(LupinContext *ctx, Lane *ln, const LupinScen
                                     uint32_t blocks, uint32_t pblocks, const StackPlan &plan, uint32_t iterations)
 {
     hipStream_t st = ln->stream;
-    hipError_t e = hipMemsetAsync(ln->pb.counts, 0, (size_t)ln->counts_capacity * LP_SHARDS * sizeof(uint32_t), st);
+    hipError_t e = hipMemsetAsync(ln->pb.counts, 0, (size_t)ln->counts_capacity * LP_SHARDS * LP_COUNT_PLANES * sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_begin, dim3(blocks), dim3(LP_BLOCK), 0, st, (const FrameParams *)ln->d_fp, ln->pb, n);
     for (uint32_t it = 0; it < iterations; it++)
@@ -436,6 +441,8 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
     if (shd && strcmp(shd, "simple") == 0) ctx->persistent_shadow = false;
     const char *ns = getenv("LUPIN_NODE_STEPS");
     if (ns) ctx->node_steps = (uint32_t)std::min(16, std::max(1, atoi(ns)));
+    ctx->node_steps = 1u | (8u << 8) | (4u << 16);   // step gates of the persistent tracer: lanes needed for a node / triangle / instance step to run
+    if (const char *sg = getenv("LUPIN_STEP_GATES")) { unsigned a = 1, b = 1, c = 1; if (sscanf(sg, "%u,%u,%u", &a, &b, &c) == 3) ctx->node_steps = (a & 0xFFu) | ((b & 0xFFu) << 8) | ((c & 0xFFu) << 16); }
     const char *slw = getenv("LUPIN_STACK_LDS_WORDS");
     if (slw) { const int v = atoi(slw); ctx->persist_lds_words = v >= 64 ? 64u : (v >= 32 ? 32u : (v >= 16 ? 16u : 8u)); }
     const char *rm = getenv("LUPIN_REFILL_MIN");
@@ -800,7 +807,7 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
         const float (*r)[4] = in.transpose_inverse_transform.m;   // 3 rows x 4: world -> local
         const double a = r[0][0], b = r[0][1], c = r[0][2], d = r[1][0], e = r[1][1], f = r[1][2], g = r[2][0], h = r[2][1], k = r[2][2];
         const double det = a * (e * k - f * h) - b * (d * k - f * g) + c * (d * h - e * g);
-        float4 bound = make_float4(0.0f, 0.0f, 0.0f, INFINITY);   // singular / non-finite transform: never culled
+        float4 bound = make_float4(0.0f, 0.0f, 0.0f, INFINITY);   // singular / non-finite transform: never culled (.w = radius squared)
         if (std::isfinite(det) && det != 0.0 && m.num_verts > 0)
         {
             const double inv[3][3] = {{(e * k - f * h) / det, (c * h - b * k) / det, (b * f - c * e) / det},
@@ -823,7 +830,8 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
                 const double cx = 0.5 * (lo[0] + hi[0]), cy = 0.5 * (lo[1] + hi[1]), cz = 0.5 * (lo[2] + hi[2]);
                 const double rad = 0.5 * std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
                 const double cmag = std::fabs(cx) + std::fabs(cy) + std::fabs(cz);
-                bound = make_float4((float)cx, (float)cy, (float)cz, (float)(rad * 1.02 + 1e-4 * (cmag + rad) + 1e-6));
+                const double padded = rad * 1.02 + 1e-4 * (cmag + rad) + 1e-6;
+                bound = make_float4((float)cx, (float)cy, (float)cz, (float)(padded * padded * (1.0 + 1e-6)));   // .w = padded radius squared
             }
         }
         light_bounds[i] = bound;
