@@ -87,11 +87,7 @@ def own_layout_bytes(kst, mode=0):
     """Bytes the tracing kernel requests per path-bounce in this build's layout, from its device-side work counters."""
     u = max(1, kst["path_bounces"])
     n, t, i = kst["node_visits"][mode] / u, kst["tri_tests"][mode] / u, kst["instance_entries"][mode] / u
-    sch = kst["sched"][mode]
     return {"node_visits": n, "tri_tests": t, "instance_entries": i,
-            "lanes_per_node_step": kst["node_visits"][mode] / max(1, sch[0]), "lanes_per_tri_step": kst["tri_tests"][mode] / max(1, sch[1]),
-            "node_steps_per_unit_x64": 64.0 * sch[0] / u, "tri_steps_per_unit_x64": 64.0 * sch[1] / u, "rounds_per_unit_x64": 64.0 * sch[3] / u,
-            "refills_per_unit_x64": 64.0 * sch[2] / u,
             "bytes_per_unit": 64.0 * n + 48.0 * t + 64.0 * i + PATH_STATE_BYTES_EXTEND}
 
 

@@ -440,9 +440,6 @@ typedef struct LupinStats {
     uint64_t node_visits[3];
     uint64_t tri_tests[3];
     uint64_t instance_entries[3];
-    /* persistent tracer, per mode: wave-level node steps, triangle steps, refills, scheduling rounds (diagnostics:
-     * lanes per node step = node_visits / sched[.][0]) */
-    uint64_t sched[3][4];
 } LupinStats;
 enum LupinStatsMode {
     LUPIN_STATS_PLAIN = 0,           /* path-bounce / path counters only (always on) */

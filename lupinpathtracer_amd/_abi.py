@@ -135,8 +135,7 @@ class TonemapDescC(C.Structure):
 class StatsC(C.Structure):
     _fields_ = [("path_bounces", C.c_uint64), ("paths", C.c_uint64), ("extend_launches", C.c_uint64),
                 ("extend_ms", C.c_double), ("shade_ms", C.c_double), ("total_ms", C.c_double),
-                ("node_visits", C.c_uint64 * 3), ("tri_tests", C.c_uint64 * 3), ("instance_entries", C.c_uint64 * 3),
-                ("sched", (C.c_uint64 * 4) * 3)]
+                ("node_visits", C.c_uint64 * 3), ("tri_tests", C.c_uint64 * 3), ("instance_entries", C.c_uint64 * 3)]
 
 
 class RuntimeInfoC(C.Structure):

@@ -245,13 +245,9 @@ LP_DEV TriHit tri_dst(f3 o, f3 d, f3 v0, f3 v1, f3 v2, float eps)
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const v4f *lds_v4p;
 constexpr uint32_t LP_GEO_LDS_LIMIT = 24 * 1024;
+constexpr uint32_t LP_GEO_LDS_STRIDE = 5;   // 16-byte words per staged node / instance record (80 bytes: see lupin_hip_scene_create)
 
 struct NodeRegs { float4 a, b, c; uint32_t left, right; };
-// One 64-byte record of any of the three kinds a traversal step needs (0 = WideNode, 1 = TriVerts + 16 bytes of whatever
-// follows, 2 = InstanceDev), fetched by ONE set of four 16-byte loads whatever the lane is about to do: the persistent
-// tracer lets every lane take its own next step in every round, and the loads of all three kinds fly together.
-struct Fetch64 { float4 w0, w1, w2, w3; };
-LP_DEV NodeRegs as_node(const Fetch64 &f) { NodeRegs r; r.a = f.w0; r.b = f.w1; r.c = f.w2; r.left = __float_as_uint(f.w3.x); r.right = __float_as_uint(f.w3.y); return r; }
 
 struct GeoGlobal
 {
@@ -263,13 +259,6 @@ struct GeoGlobal
         const WideNode nd = (in_blas ? blas : tlas)[i];
         NodeRegs r; r.a = nd.a; r.b = nd.b; r.c = nd.c; r.left = nd.d.x; r.right = nd.d.y;
         return r;
-    }
-    LP_DEV Fetch64 fetch(uint32_t kind, bool in_blas, uint32_t i) const
-    {
-        const float4 *p = kind == 0u ? reinterpret_cast<const float4 *>((in_blas ? blas : tlas) + i)
-                        : (kind == 1u ? reinterpret_cast<const float4 *>(tris + i) : reinterpret_cast<const float4 *>(instances + i));
-        Fetch64 f; f.w0 = p[0]; f.w1 = p[1]; f.w2 = p[2]; f.w3 = p[3];   // every device array is padded by 64 bytes at upload
-        return f;
     }
     LP_DEV TriVerts tri(uint32_t i) const { return tris[i]; }           // a triangle TEST fetches through tri()
     LP_DEV TriVerts tri_fetch(uint32_t i) const { return tris[i]; }     // shading re-reads vertices through tri_fetch()
@@ -284,16 +273,10 @@ struct GeoLds
     static LP_DEV float4 f4(v4f v) { return make_float4(v.x, v.y, v.z, v.w); }
     LP_DEV NodeRegs node(bool in_blas, uint32_t i) const
     {
-        lds_v4p p = base + (in_blas ? off_blas : 0u) + i * 4u;
+        lds_v4p p = base + (in_blas ? off_blas : 0u) + i * LP_GEO_LDS_STRIDE;
         const v4f a = p[0], b = p[1], c = p[2], d = p[3];
         NodeRegs r; r.a = f4(a); r.b = f4(b); r.c = f4(c); r.left = __float_as_uint(d.x); r.right = __float_as_uint(d.y);
         return r;
-    }
-    LP_DEV Fetch64 fetch(uint32_t kind, bool in_blas, uint32_t i) const
-    {
-        lds_v4p p = base + (kind == 0u ? (in_blas ? off_blas : 0u) + i * 4u : (kind == 1u ? off_tris + i * 3u : off_inst + i * 4u));
-        Fetch64 f; f.w0 = f4(p[0]); f.w1 = f4(p[1]); f.w2 = f4(p[2]); f.w3 = f4(p[3]);   // the blob ends with the instances: a triangle's 4th word exists
-        return f;
     }
     LP_DEV TriVerts tri(uint32_t i) const
     {
@@ -305,7 +288,7 @@ struct GeoLds
     static constexpr bool kCounting = false;
     LP_DEV InstanceDev inst(uint32_t i) const
     {
-        lds_v4p p = base + off_inst + i * 4u;
+        lds_v4p p = base + off_inst + i * LP_GEO_LDS_STRIDE;
         const v4f d = p[3];
         InstanceDev in; in.r0 = f4(p[0]); in.r1 = f4(p[1]); in.r2 = f4(p[2]);
         in.blas_root = __float_as_uint(d.x); in.mat_idx = __float_as_uint(d.y); in.mesh_idx = __float_as_uint(d.z); in.flags = __float_as_uint(d.w);
@@ -323,11 +306,6 @@ struct GeoCounting
     uint32_t *aabb_checks, *tri_checks;   // the calling thread's counters
     static constexpr bool kCounting = true;
     LP_DEV NodeRegs node(bool in_blas, uint32_t i) const { *aabb_checks += 2u; return base.node(in_blas, i); }
-    LP_DEV Fetch64 fetch(uint32_t kind, bool in_blas, uint32_t i) const
-    {
-        if (kind == 0u) *aabb_checks += 2u; else if (kind == 1u) *tri_checks += 1u;
-        return base.fetch(kind, in_blas, i);
-    }
     LP_DEV TriVerts tri(uint32_t i) const { *tri_checks += 1u; return base.tri(i); }
     LP_DEV TriVerts tri_fetch(uint32_t i) const { return base.tri(i); }
     LP_DEV InstanceDev inst(uint32_t i) const { return base.inst(i); }
@@ -340,10 +318,9 @@ template <typename Base>
 struct GeoTally
 {
     Base base;
-    uint32_t *tally;   // [0] node visits, [1] triangle tests, [2] instance entries ([3..7]: scheduling diagnostics of the persistent tracer)
+    uint32_t *tally;   // [0] node visits, [1] triangle tests, [2] instance entries
     static constexpr bool kCounting = false;   // light culling stays on: the tally is of the work actually done
     LP_DEV NodeRegs node(bool in_blas, uint32_t i) const { tally[0] += 1u; return base.node(in_blas, i); }
-    LP_DEV Fetch64 fetch(uint32_t kind, bool in_blas, uint32_t i) const { tally[kind] += 1u; return base.fetch(kind, in_blas, i); }
     LP_DEV TriVerts tri(uint32_t i) const { tally[1] += 1u; return base.tri(i); }
     LP_DEV TriVerts tri_fetch(uint32_t i) const { return base.tri_fetch(i); }
     LP_DEV InstanceDev inst(uint32_t i) const { tally[2] += 1u; return base.inst(i); }
@@ -381,40 +358,6 @@ struct Closest
     float t, u, v;
     uint32_t tri;   // global triangle index
     uint32_t inst;
-};
-
-// Stack of the persistent tracer: the newest `mask + 1` words of every lane live in an LDS ring (word e at ring slot
-// e & mask, lane t at ring[slot * LP_BLOCK + t]: bank = t mod 32 at every depth), older words in global memory.  A scene's
-// worst case (its hierarchy depth, 39 for the bistro-class scene) sized the LDS stack of round 1 and with it the number of
-// resident blocks; a ray rarely holds more than a dozen entries, and this kernel lives on the number of rays it keeps in
-// flight.  Invariant: floor <= sp <= floor + mask + 1.  Before a push the oldest 8 words are moved out if the ring is
-// full, before a pop they are brought back if the ring is empty: rare, divergent slow paths.
-struct RingStack
-{
-    uint32_t *lds;        // + threadIdx.x
-    uint32_t *overflow;   // + global thread index; word e at overflow[e * threads]
-    uint32_t mask, threads;
-    uint32_t floor;       // oldest word still in the ring (multiple of 8)
-    LP_DEV void push(uint32_t &sp, uint32_t v)
-    {
-        if (sp == floor + mask + 1u)
-        {
-            for (uint32_t k = 0; k < 8u; k++) overflow[(size_t)(floor + k) * threads] = lds[((floor + k) & mask) * LP_BLOCK];
-            floor += 8u;
-        }
-        lds[(sp & mask) * LP_BLOCK] = v;
-        sp++;
-    }
-    LP_DEV uint32_t pop(uint32_t &sp)
-    {
-        if (sp == floor && floor != 0u)
-        {
-            floor -= 8u;
-            for (uint32_t k = 0; k < 8u; k++) lds[((floor + k) & mask) * LP_BLOCK] = overflow[(size_t)(floor + k) * threads];
-        }
-        sp--;
-        return lds[(sp & mask) * LP_BLOCK];
-    }
 };
 
 // Descend one BLAS (bvh_custom.wgsl:195-288) from `root`, updating `best` on strictly closer hits.
@@ -1513,11 +1456,7 @@ LP_FN float lights_pdf(const Geo &geo, const SceneDev &sc, uint32_t *stack, f3 p
     // candidates in increasing light order, so the sum below has the reference's order and the skipped terms are +0.0f.
     float mesh_pdf = 0.0f;
     const float dd = dot3(incoming, incoming);
-#ifdef LP_EXPERIMENT_SKIP_MESH_LIGHT_PDF   // timing experiment only: how much of k_shade is culling + marching?
-    for (uint32_t base = 0; base < 0u; base += 32u)
-#else
     for (uint32_t base = 0; base < sc.num_lights; base += 32u)
-#endif
     {
         const uint32_t cnt = (sc.num_lights - base) < 32u ? (sc.num_lights - base) : 32u;
         uint32_t mask = 0u;
@@ -1536,10 +1475,6 @@ LP_FN float lights_pdf(const Geo &geo, const SceneDev &sc, uint32_t *stack, f3 p
             // (the debug heat maps count every light's tests, so the counting accessor keeps them all)
             if (Geo::kCounting || reach) mask |= 1u << k;
         }
-#ifdef LP_EXPERIMENT_SKIP_LIGHT_MARCH   // timing experiment only: culling without the marching
-        mesh_pdf += (float)__builtin_popcount(mask) * 1e-9f;
-        mask = 0u;
-#endif
         while (mask)
         {
         const uint32_t i = base + (uint32_t)__builtin_ctz(mask);

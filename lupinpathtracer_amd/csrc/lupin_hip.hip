@@ -29,8 +29,7 @@ static int fail(int code, const std::string &msg) { g_last_error = msg; return c
 #define HIP_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return fail(LUPIN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } while (0)
 
 #define LP_MAX_LANES 4
-#define LP_COUNT_PLANES 4   // PathBuffers::counts: the queue counts + one plane of work cursors per persistent-tracer mode
-#define LP_WORK_WORDS 24   // 3 tracing modes (closest hit | shadow rays | light-pdf marching) x {nodes, triangles, instances, -, node steps, triangle steps, refills, rounds}
+#define LP_WORK_WORDS 12   // 3 tracing modes (closest hit | shadow rays | light-pdf marching) x {nodes, triangles, instances}, padded
 // "Lanes" (stream + path buffers + counters) let consecutive pathtrace_scene calls overlap: the wavefront of
 // frame k+1 starts while the thin tail of frame k is still draining.  Frames only meet at k_resolve (frame k+1 blends
 // with frame k's output), which waits on the previous call's completion event.
@@ -41,8 +40,6 @@ struct Lane
     uint64_t capacity = 0;          // slots the path buffers hold
     uint32_t counts_capacity = 0;
     unsigned long long *stat_counters = nullptr;   // per shard: [2s] path bounces, [2s+1] paths
-    uint32_t *stack_overflow = nullptr;            // deep tail of the persistent tracer's traversal stacks (RingStack)
-    uint64_t overflow_capacity = 0;                // words
     unsigned long long *work_counters = nullptr;   // [3 * mode + {nodes, triangles, instances}] of the COUNT kernels (stats mode 2)
     hipEvent_t done = nullptr;      // recorded after the last kernel of the lane's latest call
     bool used = false;
@@ -52,7 +49,7 @@ struct Lane
     struct GraphKey
     {
         uint64_t scene_id = 0, pb_generation = 0;
-        uint32_t n = 0, blocks = 0, type = 0, iterations = 0, full_words = 0, light_words = 0, persist_words = 0, blob_bytes = 0, pblocks = 0, refill_min = 0, node_steps = 0;
+        uint32_t n = 0, blocks = 0, type = 0, iterations = 0, stack_words = 0, lds = 0, pblocks = 0, refill_min = 0, node_steps = 0;
         int persistent = 0, persistent_shadow = 0, lds_geometry = 0;
         bool operator==(const GraphKey &o) const { return memcmp(this, &o, sizeof(GraphKey)) == 0; }
     } graph_key, seen_key;           // key of graph_exec | key of the lane's previous call
@@ -83,7 +80,6 @@ struct LupinContext
     bool use_graph = false;                 // LUPIN_GRAPH=1: replay the lane-private wavefront as a HIP graph (opt-in)
     bool persistent_shadow = true;          // LUPIN_SHADOW=simple: MIS / Direct shadow rays stay in k_shadow even on large scenes
     uint32_t node_steps = 4;               // LUPIN_NODE_STEPS: node visits per scheduling round of k_extend_persistent
-    uint32_t persist_lds_words = 16;       // LUPIN_STACK_LDS_WORDS (8 | 16 | 32 | 64): traversal-stack ring of the persistent tracer, words per lane in LDS
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_extend, ev_shade, ev_total;
     std::vector<hipEvent_t> ev_pool;
     uint64_t extend_launches = 0;
@@ -107,8 +103,7 @@ struct LupinScene
     LupinContext *ctx;
     SceneDev dev{};
     std::vector<void *> allocations;
-    uint32_t stack_entries = 1;                     // worst-case traversal-stack words of a closest-hit query (TLAS depth + deepest BLAS + 1)
-    uint32_t light_stack_entries = 1;               // ... of light-pdf marching (the deepest BLAS of an emissive instance + 1)
+    uint32_t stack_entries = 1;
     uint32_t persistent_blocks[4] = {0, 0, 0, 0};   // grid of k_extend_persistent per integrator (lazy)
     uint64_t id = 0;                                // unique per created scene (graph cache key)
     bool all_opaque = false;                        // no instance can have opacity != 1: k_extend<.., OPAQUE> drops the alpha test
@@ -121,7 +116,7 @@ template <typename T>
 static int upload(LupinScene *sc, const std::vector<T> &host, const T **out)
 {
     *out = nullptr;
-    size_t bytes = std::max<size_t>(host.size() * sizeof(T), sizeof(T) > 16 ? sizeof(T) : 16) + 64;   // + 64: Geo::fetch reads whole 64-byte records
+    size_t bytes = std::max<size_t>(host.size() * sizeof(T), sizeof(T) > 16 ? sizeof(T) : 16);
     void *d = nullptr;
     HIP_TRY(hipMalloc(&d, bytes));
     sc->allocations.push_back(d);
@@ -167,9 +162,8 @@ static int ensure_path_buffers(LupinContext *ctx0, Lane *ctx, uint64_t slots, ui
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->pb.counts) hipFree(ctx->pb.counts);
         ctx->pb.counts = nullptr;
-        HIP_TRY(hipMalloc((void **)&ctx->pb.counts, (size_t)(iterations + 2) * LP_SHARDS * LP_COUNT_PLANES * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **)&ctx->pb.counts, (size_t)(iterations + 2) * LP_SHARDS * sizeof(uint32_t)));
         ctx->counts_capacity = iterations + 2;
-        ctx->pb.counts_stride = (iterations + 2) * LP_SHARDS;
         ctx->pb_generation++;
     }
     return LUPIN_OK;
@@ -199,15 +193,6 @@ static uint32_t blas_depth(const LupinBvhNode *nodes, uint32_t count)
     return best;
 }
 
-// Dynamic LDS of the stage kernels: [traversal stack words x LP_BLOCK][geometry blob, if staged].  Each kernel sizes the
-// stack for the traversals it runs: closest-hit kernels the scene's worst case, k_shade the light-pdf marching of one
-// BLAS, the persistent tracer a small ring (the deep tail goes to global memory, RingStack).
-struct StackPlan
-{
-    uint32_t full_words = 1, light_words = 1, persist_words = 1, blob_bytes = 0;
-    size_t lds(uint32_t words) const { return (size_t)words * LP_BLOCK * sizeof(uint32_t) + blob_bytes; }
-};
-
 // grid of the persistent tracer: as many blocks as the device keeps resident with this scene's traversal-stack size
 // (whole waves per shard); queried once per scene and integrator, outside any stream capture
 template <int TYPE, bool LDSGEO>
@@ -218,13 +203,10 @@ static uint32_t persistent_grid_t(LupinContext *ctx, const LupinScene *scene, si
     {
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extend_persistent<TYPE, LDSGEO, 0, false>, LP_BLOCK, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-        // The tracer is latency-bound: throughput grows with the rays in flight (bistro-class, serial kernel time per two 4K
-        // frames: 354 / 297 / 269 ms at 3 / 4 / 5 blocks per CU), but with frames in flight its blocks share the CU with the
-        // shading of another frame: whole-frame throughput is flat from 4 blocks on (226 vs 229 ms per step), and small
-        // scenes whose rays finish quickly prefer to leave room (materials1 / environments1 +5 % with 3).  With the LDS
-        // ring stack five blocks fit for every scene (86 VGPRs); four are used when the scene is traversed from global
-        // memory, three when its geometry is staged in LDS.
-        if (ctx->num_lanes > 1 && per_cu > 4) per_cu = LDSGEO ? 3 : 4;
+        // With frames in flight the persistent tracer of one frame shares the chip with the shading of another: when five
+        // or more of its blocks fit per CU, three leave that room and the pair finishes sooner (materials1 / environments1
+        // +5 %); deeper scenes fit four at most and are latency-bound, they keep them all (bistro-class -9 % with two).
+        if (ctx->num_lanes > 1 && per_cu > 4) per_cu = 3;
         if (ctx->blocks_per_cu_override > 0) per_cu = ctx->blocks_per_cu_override;
         cached = std::max(64u, ctx->num_cus * (uint32_t)per_cu / 64u * 64u);
     }
@@ -244,10 +226,8 @@ static uint32_t persistent_grid(LupinContext *ctx, const LupinScene *scene, uint
 }
 
 template <int TYPE, bool LDSGEO>
-static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *scene, uint32_t blocks, uint32_t pblocks, const StackPlan &plan, uint32_t iter)
+static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *scene, uint32_t blocks, uint32_t pblocks, size_t lds, uint32_t stack_words, uint32_t iter)
 {
-    const size_t lds = plan.lds(plan.full_words), lds_p = plan.lds(plan.persist_words), lds_s = plan.lds(plan.light_words);
-    const uint32_t stack_words = plan.full_words * LP_BLOCK, stack_words_p = plan.persist_words * LP_BLOCK, stack_words_s = plan.light_words * LP_BLOCK;
     hipStream_t st = ln->stream;
     const FrameParams *fp = ln->d_fp;
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
@@ -257,11 +237,11 @@ static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *sc
     if (persistent)
     {
         if (ctx->counting)
-            hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, 0, true>), dim3(pblocks), dim3(LP_BLOCK), lds_p, st,
-                               scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words_p, ctx->node_steps, work, ln->stack_overflow);
+            hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, 0, true>), dim3(pblocks), dim3(LP_BLOCK), lds, st,
+                               scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words, ctx->node_steps, work);
         else
-            hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, 0, false>), dim3(pblocks), dim3(LP_BLOCK), lds_p, st,
-                               scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words_p, ctx->node_steps, work, ln->stack_overflow);
+            hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, 0, false>), dim3(pblocks), dim3(LP_BLOCK), lds, st,
+                               scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words, ctx->node_steps, work);
     }
     else
     {
@@ -278,21 +258,21 @@ static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *sc
     }
     if (ctx->timing) hipEventRecord(e1, st);
     if (scene->simple_matte && ctx->specialize_simple)
-        hipLaunchKernelGGL((k_shade<TYPE, LDSGEO, true>), dim3(blocks), dim3(LP_BLOCK), lds_s, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words_s);
+        hipLaunchKernelGGL((k_shade<TYPE, LDSGEO, true>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
     else
-        hipLaunchKernelGGL((k_shade<TYPE, LDSGEO, false>), dim3(blocks), dim3(LP_BLOCK), lds_s, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words_s);
+        hipLaunchKernelGGL((k_shade<TYPE, LDSGEO, false>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
     if constexpr (TYPE == LUPIN_PATHTRACE_MIS || TYPE == LUPIN_PATHTRACE_DIRECT)   // shadow rays + path finish (booked with "shade" in the timing)
     {
         if (persistent && ctx->persistent_shadow)
         {
             // large scenes: the shadow rays go through the phase-scheduled persistent tracer as well, then a light finish pass
             if (ctx->counting)
-                hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, 1, true>), dim3(pblocks), dim3(LP_BLOCK), lds_p, st,
-                                   scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words_p, ctx->node_steps, work, ln->stack_overflow);
+                hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, 1, true>), dim3(pblocks), dim3(LP_BLOCK), lds, st,
+                                   scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words, ctx->node_steps, work);
             else
-                hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, 1, false>), dim3(pblocks), dim3(LP_BLOCK), lds_p, st,
-                                   scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words_p, ctx->node_steps, work, ln->stack_overflow);
-            hipLaunchKernelGGL((k_shadow<TYPE, LDSGEO, true>), dim3(blocks), dim3(LP_BLOCK), lds_s, st, scene->dev, fp, ln->pb, iter, stack_words_s);   // no traversal: the rays were traced above
+                hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, 1, false>), dim3(pblocks), dim3(LP_BLOCK), lds, st,
+                                   scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words, ctx->node_steps, work);
+            hipLaunchKernelGGL((k_shadow<TYPE, LDSGEO, true>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, stack_words);
         }
         else
             hipLaunchKernelGGL((k_shadow<TYPE, LDSGEO, false>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, stack_words);
@@ -307,28 +287,28 @@ static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *sc
 }
 
 template <int TYPE>
-static void launch_iteration(LupinContext *ctx, Lane *ln, const LupinScene *scene, bool lds_geo, uint32_t blocks, uint32_t pblocks, const StackPlan &plan, uint32_t iter)
+static void launch_iteration(LupinContext *ctx, Lane *ln, const LupinScene *scene, bool lds_geo, uint32_t blocks, uint32_t pblocks, size_t lds, uint32_t stack_words, uint32_t iter)
 {
-    if (lds_geo) launch_iteration_t<TYPE, true>(ctx, ln, scene, blocks, pblocks, plan, iter);
-    else launch_iteration_t<TYPE, false>(ctx, ln, scene, blocks, pblocks, plan, iter);
+    if (lds_geo) launch_iteration_t<TYPE, true>(ctx, ln, scene, blocks, pblocks, lds, stack_words, iter);
+    else launch_iteration_t<TYPE, false>(ctx, ln, scene, blocks, pblocks, lds, stack_words, iter);
 }
 
 // the lane-private part of one call: clear the queue counters, first rays, every iteration of the wavefront
 static hipError_t enqueue_wavefront(LupinContext *ctx, Lane *ln, const LupinScene *scene, uint32_t pathtrace_type, bool lds_geo, uint32_t n,
-                                    uint32_t blocks, uint32_t pblocks, const StackPlan &plan, uint32_t iterations)
+                                    uint32_t blocks, uint32_t pblocks, size_t lds, uint32_t stack_words, uint32_t iterations)
 {
     hipStream_t st = ln->stream;
-    hipError_t e = hipMemsetAsync(ln->pb.counts, 0, (size_t)ln->counts_capacity * LP_SHARDS * LP_COUNT_PLANES * sizeof(uint32_t), st);
+    hipError_t e = hipMemsetAsync(ln->pb.counts, 0, (size_t)ln->counts_capacity * LP_SHARDS * sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_begin, dim3(blocks), dim3(LP_BLOCK), 0, st, (const FrameParams *)ln->d_fp, ln->pb, n);
     for (uint32_t it = 0; it < iterations; it++)
     {
         switch (pathtrace_type)
         {
-        case LUPIN_PATHTRACE_STANDARD: launch_iteration<LUPIN_PATHTRACE_STANDARD>(ctx, ln, scene, lds_geo, blocks, pblocks, plan, it); break;
-        case LUPIN_PATHTRACE_MIS: launch_iteration<LUPIN_PATHTRACE_MIS>(ctx, ln, scene, lds_geo, blocks, pblocks, plan, it); break;
-        case LUPIN_PATHTRACE_NAIVE: launch_iteration<LUPIN_PATHTRACE_NAIVE>(ctx, ln, scene, lds_geo, blocks, pblocks, plan, it); break;
-        default: launch_iteration<LUPIN_PATHTRACE_DIRECT>(ctx, ln, scene, lds_geo, blocks, pblocks, plan, it); break;
+        case LUPIN_PATHTRACE_STANDARD: launch_iteration<LUPIN_PATHTRACE_STANDARD>(ctx, ln, scene, lds_geo, blocks, pblocks, lds, stack_words, it); break;
+        case LUPIN_PATHTRACE_MIS: launch_iteration<LUPIN_PATHTRACE_MIS>(ctx, ln, scene, lds_geo, blocks, pblocks, lds, stack_words, it); break;
+        case LUPIN_PATHTRACE_NAIVE: launch_iteration<LUPIN_PATHTRACE_NAIVE>(ctx, ln, scene, lds_geo, blocks, pblocks, lds, stack_words, it); break;
+        default: launch_iteration<LUPIN_PATHTRACE_DIRECT>(ctx, ln, scene, lds_geo, blocks, pblocks, lds, stack_words, it); break;
         }
     }
     return hipSuccess;
@@ -441,10 +421,6 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
     if (shd && strcmp(shd, "simple") == 0) ctx->persistent_shadow = false;
     const char *ns = getenv("LUPIN_NODE_STEPS");
     if (ns) ctx->node_steps = (uint32_t)std::min(16, std::max(1, atoi(ns)));
-    ctx->node_steps = 1u | (8u << 8) | (4u << 16);   // step gates of the persistent tracer: lanes needed for a node / triangle / instance step to run
-    if (const char *sg = getenv("LUPIN_STEP_GATES")) { unsigned a = 1, b = 1, c = 1; if (sscanf(sg, "%u,%u,%u", &a, &b, &c) == 3) ctx->node_steps = (a & 0xFFu) | ((b & 0xFFu) << 8) | ((c & 0xFFu) << 16); }
-    const char *slw = getenv("LUPIN_STACK_LDS_WORDS");
-    if (slw) { const int v = atoi(slw); ctx->persist_lds_words = v >= 64 ? 64u : (v >= 32 ? 32u : (v >= 16 ? 16u : 8u)); }
     const char *rm = getenv("LUPIN_REFILL_MIN");
     if (rm) ctx->refill_min = (uint32_t)std::min(64, std::max(1, atoi(rm)));
     *out_ctx = ctx;
@@ -461,7 +437,7 @@ void lupin_hip_destroy_context(LupinContext *ctx)
         PathBuffers &pb = ctx->lanes[k].pb;
         void *ptrs[] = {pb.ori_rng, pb.dir_meta, pb.weight, pb.radiance, pb.color, pb.hit, pb.hit_tri, pb.vol0, pb.vol1,
                         pb.next_hit, pb.next_tri, pb.queue[0], pb.queue[1], pb.counts, ctx->lanes[k].stat_counters,
-                        pb.sh_org, pb.sh_d0, pb.sh_f0, pb.sh_d1, pb.sh_f1, pb.sh_hit1, ctx->lanes[k].work_counters, ctx->lanes[k].stack_overflow};
+                        pb.sh_org, pb.sh_d0, pb.sh_f0, pb.sh_d1, pb.sh_f1, pb.sh_hit1, ctx->lanes[k].work_counters};
         for (void *p : ptrs) if (p) hipFree(p);
         if (ctx->lanes[k].done) hipEventDestroy(ctx->lanes[k].done);
         if (ctx->lanes[k].graph_exec) hipGraphExecDestroy(ctx->lanes[k].graph_exec);
@@ -592,7 +568,6 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
     std::vector<MeshDev> meshes(s.num_meshes);
     std::vector<uint32_t> mesh_root(s.num_meshes);
     uint32_t max_blas_depth = 0;
-    std::vector<uint32_t> mesh_depth(s.num_meshes, 0u);
     for (uint32_t mi = 0; mi < s.num_meshes; mi++)
     {
         const LupinMeshDesc &m = s.meshes[mi];
@@ -676,7 +651,6 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
         const uint32_t bd = blas_depth(m.bvh_nodes, m.num_bvh_nodes);
         if (bd == 0xFFFFFFFFu) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "BLAS is not a tree"); }
         max_blas_depth = std::max(max_blas_depth, bd);
-        mesh_depth[mi] = bd;
     }
 
     // ---- TLAS ----
@@ -796,9 +770,6 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
     // Conservative world-space bounding sphere of every light instance (all mesh vertices through the inverse of the
     // stored world->local rows, in double, radius padded): lights_pdf skips lights whose sphere the ray cannot reach.
     // A skipped light contributes exactly +0.0f in the reference's sum, so results do not change.
-    uint32_t light_words = 1;
-    for (uint32_t i = 0; i < s.num_lights; i++) light_words = std::max(light_words, mesh_depth[s.instances[s.lights[i].instance_idx].mesh_idx] + 1);
-    sc->light_stack_entries = light_words;
     std::vector<float4> light_bounds(s.num_lights);
     for (uint32_t i = 0; i < s.num_lights; i++)
     {
@@ -837,24 +808,32 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
         light_bounds[i] = bound;
     }
 
-    // small scenes: one blob [tlas | blas | tris | instances] in 16-byte words for LDS staging
+    // small scenes: one blob [tlas | blas | tris | instances] in 16-byte words for LDS staging.  Nodes and instances are
+    // laid out at a stride of FIVE words (80 bytes) instead of four: a wave's lanes read records at divergent indices with
+    // ds_read_b128, and at a 64-byte stride records i and i + 4 start in the same LDS bank (round 1's PMC: 62 M
+    // SQ_LDS_BANK_CONFLICT cycles against 184 M SQ_ACTIVE_INST_LDS on the Cornell box); at 80 bytes only i and i + 16
+    // collide.  Triangles keep 48 bytes (3 words: i and i + 16 collide as well).
     std::vector<float4> geo_blob;
     uint32_t off_blas = 0, off_tris = 0, off_inst = 0;
     {
-        const size_t bytes = tlas.size() * 64 + blas.size() * 64 + tris.size() * 48 + instances.size() * 64;
+        const size_t bytes = tlas.size() * 80 + blas.size() * 80 + tris.size() * 48 + instances.size() * 80;
         if (bytes > 0 && bytes <= LP_GEO_LDS_LIMIT)
         {
-            auto append = [&](const void *p, size_t nbytes) {
+            auto append = [&](const void *p, size_t count, size_t words) {   // records of `words` 16-byte words, padded to LP_GEO_LDS_STRIDE
                 const float4 *f = reinterpret_cast<const float4 *>(p);
-                geo_blob.insert(geo_blob.end(), f, f + nbytes / 16);
+                for (size_t r = 0; r < count; r++)
+                {
+                    geo_blob.insert(geo_blob.end(), f + r * words, f + (r + 1) * words);
+                    if (words == 4) geo_blob.push_back(make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+                }
             };
-            append(tlas.data(), tlas.size() * 64);
+            append(tlas.data(), tlas.size(), 4);
             off_blas = (uint32_t)geo_blob.size();
-            append(blas.data(), blas.size() * 64);
+            append(blas.data(), blas.size(), 4);
             off_tris = (uint32_t)geo_blob.size();
-            append(tris.data(), tris.size() * 48);
+            append(tris.data(), tris.size(), 3);
             off_inst = (uint32_t)geo_blob.size();
-            append(instances.data(), instances.size() * 64);
+            append(instances.data(), instances.size(), 4);
         }
     }
 
@@ -1152,35 +1131,15 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
     const uint32_t blocks_per_shard = (blocks_needed + LP_SHARDS - 1) / LP_SHARDS;
     const uint32_t blocks = blocks_per_shard * LP_SHARDS;
     ln->pb.shard_cap = blocks_per_shard * LP_BLOCK;
+    const uint32_t stack_words = scene->stack_entries * LP_BLOCK;
     const bool lds_geo = scene->dev.geo_blob_words && ctx->lds_geometry;
-    StackPlan plan;
-    plan.full_words = scene->stack_entries;
-    plan.light_words = scene->light_stack_entries;
-    plan.persist_words = ctx->persist_lds_words;   // an LDS ring (power of two); the deep tail lives in Lane::stack_overflow
-    plan.blob_bytes = lds_geo ? scene->dev.geo_blob_words * 16u : 0u;
-    const bool persistent_path = use_persistent(ctx, lds_geo);
-    const size_t lds = persistent_path ? plan.lds(plan.persist_words) : plan.lds(plan.full_words);   // the closest-hit kernel's
-    const bool all_traced_persistently = persistent_path && (pathtrace_type == LUPIN_PATHTRACE_STANDARD || pathtrace_type == LUPIN_PATHTRACE_NAIVE || ctx->persistent_shadow);
-    if (plan.lds(all_traced_persistently ? std::max(plan.persist_words, plan.light_words) : plan.full_words) > 160 * 1024)
-        return fail(LUPIN_ERR_INVALID_ARGUMENT, "BVH too deep for the LDS traversal stack");
+    const size_t lds = (size_t)stack_words * sizeof(uint32_t) + (lds_geo ? (size_t)scene->dev.geo_blob_words * 16 : 0);
+    if (lds > 160 * 1024) return fail(LUPIN_ERR_INVALID_ARGUMENT, "BVH too deep for the LDS traversal stack");
 
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (ctx->timing) { t0 = get_event(ctx); t1 = get_event(ctx); hipEventRecord(t0, st); }
 
     const uint32_t pblocks = persistent_grid(ctx, scene, pathtrace_type, lds_geo, lds);
-    if (pblocks)
-    {
-        // deep tail of the persistent tracer's stacks: the scene's worst case per resident thread (RingStack indexes it by absolute depth)
-        const uint64_t need = (uint64_t)(plan.full_words + 8u) * pblocks * LP_BLOCK;
-        if (need > ln->overflow_capacity)
-        {
-            HIP_TRY(hipStreamSynchronize(st));
-            if (ln->stack_overflow) { hipFree(ln->stack_overflow); ln->stack_overflow = nullptr; ln->overflow_capacity = 0; }
-            HIP_TRY(hipMalloc((void **)&ln->stack_overflow, need * sizeof(uint32_t)));
-            ln->overflow_capacity = need;
-            ln->pb_generation++;
-        }
-    }
     hipLaunchKernelGGL(k_set_params, dim3(1), dim3(1), 0, st, fp, ln->d_fp);
     if (ctx->use_graph && !ctx->timing && !ctx->counting)
     {
@@ -1188,8 +1147,7 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
         // (scene, dispatch size, integrator, buffers) and replayed: one graph launch instead of 2-4 launches per iteration.
         Lane::GraphKey key;
         key.scene_id = scene->id; key.pb_generation = ln->pb_generation; key.n = n; key.blocks = blocks; key.type = pathtrace_type;
-        key.iterations = iterations; key.full_words = plan.full_words; key.light_words = plan.light_words; key.persist_words = plan.persist_words;
-        key.blob_bytes = plan.blob_bytes; key.pblocks = pblocks;
+        key.iterations = iterations; key.stack_words = stack_words; key.lds = (uint32_t)lds; key.pblocks = pblocks;
         key.refill_min = ctx->refill_min; key.node_steps = ctx->node_steps; key.persistent = ctx->persistent_extend;
         key.persistent_shadow = ctx->persistent_shadow ? 1 : 0; key.lds_geometry = lds_geo ? 1 : 0;
         const bool have = ln->graph_exec && key == ln->graph_key;
@@ -1198,7 +1156,7 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
             // the lane holds a graph of another shape and this one is new (shapes alternate, e.g. edge tiles): capturing
             // costs about a millisecond, so launch directly and re-capture only if the shape repeats
             ln->seen_key = key;
-            HIP_TRY(enqueue_wavefront(ctx, ln, scene, pathtrace_type, lds_geo, n, blocks, pblocks, plan, iterations));
+            HIP_TRY(enqueue_wavefront(ctx, ln, scene, pathtrace_type, lds_geo, n, blocks, pblocks, lds, stack_words, iterations));
         }
         else
         {
@@ -1207,7 +1165,7 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
                 if (ln->graph_exec) { hipGraphExecDestroy(ln->graph_exec); ln->graph_exec = nullptr; }
                 if (ln->graph) { hipGraphDestroy(ln->graph); ln->graph = nullptr; }
                 HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-                hipError_t ce = enqueue_wavefront(ctx, ln, scene, pathtrace_type, lds_geo, n, blocks, pblocks, plan, iterations);
+                hipError_t ce = enqueue_wavefront(ctx, ln, scene, pathtrace_type, lds_geo, n, blocks, pblocks, lds, stack_words, iterations);
                 hipError_t ee = hipStreamEndCapture(st, &ln->graph);
                 if (ce != hipSuccess || ee != hipSuccess) return fail(LUPIN_ERR_HIP, std::string("graph capture: ") + hipGetErrorString(ce != hipSuccess ? ce : ee));
                 HIP_TRY(hipGraphInstantiate(&ln->graph_exec, ln->graph, nullptr, nullptr, 0));
@@ -1219,7 +1177,7 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
         }
     }
     else
-        HIP_TRY(enqueue_wavefront(ctx, ln, scene, pathtrace_type, lds_geo, n, blocks, pblocks, plan, iterations));
+        HIP_TRY(enqueue_wavefront(ctx, ln, scene, pathtrace_type, lds_geo, n, blocks, pblocks, lds, stack_words, iterations));
     // The frames meet here: the resolve reads prev_frame and overwrites render_target, so it is ordered after everything
     // enqueued so far on the other lane (the previous call's resolve) and, for lane 1, on the primary stream (texture
     // uploads / copies).  The path state itself is private to the lane.
@@ -1320,7 +1278,7 @@ int lupin_hip_stats_get(LupinContext *ctx, LupinStats *out)
     {
         unsigned long long w[LP_WORK_WORDS];
         HIP_TRY(hipMemcpy(w, ctx->lanes[l].work_counters, sizeof(w), hipMemcpyDeviceToHost));
-        for (int m = 0; m < 3; m++) { out->node_visits[m] += w[8 * m + 0]; out->tri_tests[m] += w[8 * m + 1]; out->instance_entries[m] += w[8 * m + 2]; for (int k = 0; k < 4; k++) out->sched[m][k] += w[8 * m + 4 + k]; }
+        for (int m = 0; m < 3; m++) { out->node_visits[m] += w[3 * m + 0]; out->tri_tests[m] += w[3 * m + 1]; out->instance_entries[m] += w[3 * m + 2]; }
     }
     out->extend_launches = ctx->extend_launches;
     auto sum = [](const std::vector<std::pair<hipEvent_t, hipEvent_t>> &v) {
@@ -1346,7 +1304,7 @@ int lupin_hip_measure_copy_bandwidth(LupinContext *ctx, uint64_t bytes, uint32_t
     if (e != hipSuccess) { if (a) hipFree(a); return fail(LUPIN_ERR_OUT_OF_MEMORY, hipGetErrorString(e)); }
     hipEvent_t e0 = get_event(ctx), e1 = get_event(ctx);
     HIP_TRY(hipMemsetAsync(a, 0x3C, n * 16, ctx->stream));
-    const uint32_t blocks = ctx->num_cus * 16;
+    const uint32_t blocks = (uint32_t)((n + LP_BLOCK - 1) / LP_BLOCK);   // one 16-byte element per thread: the shape that reaches the guide's 6.29 TB/s (tools/calib/copy_probe.hip)
     hipLaunchKernelGGL(k_copy_bw, dim3(blocks), dim3(LP_BLOCK), 0, ctx->stream, (const float4 *)a, b, n);   // warm-up: pages touched
     HIP_TRY(hipEventRecord(e0, ctx->stream));
     for (uint32_t r = 0; r < reps; r++)

@@ -66,7 +66,6 @@ struct PathBuffers
     uint32_t *queue[2];   // [parity][shard * shard_cap + i]
     uint32_t *counts;     // counts[k * LP_SHARDS + s] = live paths of shard s entering iteration k
     uint32_t shard_cap;   // slots per shard (multiple of LP_BLOCK)
-    uint32_t counts_stride;   // words per plane of `counts`: plane 0 = the counts, plane 1 + m = the persistent tracer's work cursors of mode m
 };
 
 #ifndef LP_NUM_SHARDS
@@ -260,13 +259,12 @@ __device__ __forceinline__ void trace_alpha(const Geo &geo, const SceneDev &sc, 
 }
 
 // Work counters (bench.py's roofline numerator, lupin_hip_stats_reset(ctx, 2)): the COUNT instantiations of the tracing
-// kernels wrap their geometry accessor in GeoTally and add the wave's totals to work[8 * mode + {0 nodes, 1 triangles, 2 instances,
-// 4 wave-level node steps, 5 triangle steps, 6 refills, 7 scheduling rounds}].
+// kernels wrap their geometry accessor in GeoTally and add the wave's totals to work[3 * mode + {0 nodes, 1 triangles, 2 instances}].
 // All 64 lanes must be active when this is called.
-__device__ __forceinline__ void tally_flush(const uint32_t (&tally)[8], unsigned long long *work)
+__device__ __forceinline__ void tally_flush(const uint32_t (&tally)[3], unsigned long long *work)
 {
     #pragma unroll
-    for (int k = 0; k < 8; k++)
+    for (int k = 0; k < 3; k++)
     {
         uint32_t v = tally[k];
         #pragma unroll
@@ -290,7 +288,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launc
     const FrameParams fp = *fpp;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     const auto base_geo = make_geo<LDSGEO>(sc, lds_stack, stack_words);
-    uint32_t tally[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    uint32_t tally[3] = {0u, 0u, 0u};
     const auto geo = with_tally<COUNT>(base_geo, tally);
     const uint32_t shard = blockIdx.x % LP_SHARDS;
     const uint32_t count = pb.counts[iter * LP_SHARDS + shard];
@@ -327,11 +325,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launc
 // one-ray-per-lane kernel keeps 11 % of the VALU lanes busy on the bistro-class scene (39 % on the Cornell box; PMC:
 // SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU * 64)).  Here each wave owns its lanes for the whole launch, refills empty
 // lanes whenever at least `refill_min` of them are free, and executes per round the one phase most lanes wait for.
-// Work is handed out dynamically: the waves of a shard (grid waves / LP_SHARDS of them) share one cursor into that shard's
-// queue and take as many entries as they have free lanes with one atomic per refill, so a wave whose rays are short keeps
-// taking work while another is stuck on long ones (round 1 partitioned statically: the launch then lasted as long as its
-// unluckiest wave).  Every ray is still traced by exactly the same sequence of operations as in k_extend, only by a
-// different lane, so which wave takes which entry cannot change a result.
+// Work is partitioned statically, so refilling needs no atomics: the grid holds `wps` waves per shard, and wave j of
+// shard s owns the 64-entry chunks j, j + wps, j + 2 wps, ... of that shard's queue.  Every ray is still traced by
+// exactly the same sequence of operations as in k_extend, only by a different lane.
 #ifndef LP_REFILL_MIN
 #define LP_REFILL_MIN 16
 #endif
@@ -343,17 +339,13 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launc
 template <int TYPE, bool LDSGEO, int MODE, bool COUNT>
 __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, const FrameParams *__restrict__ fpp, PathBuffers pb, uint32_t iter,
                                                                 unsigned long long *shard_stats, uint32_t refill_min, uint32_t stack_words, uint32_t nsteps,
-                                                                unsigned long long *work, uint32_t *stack_overflow)
+                                                                unsigned long long *work)
 {
     const FrameParams fp = *fpp;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     const auto base_geo = make_geo<LDSGEO>(sc, lds_stack, stack_words);
-    uint32_t tally[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    uint32_t tally[3] = {0u, 0u, 0u};
     const auto geo = with_tally<COUNT>(base_geo, tally);
-    const uint32_t gate_n = nsteps & 0xFFu, gate_t = (nsteps >> 8) & 0xFFu, gate_i = (nsteps >> 16) & 0xFFu;   // LUPIN_STEP_GATES
-    RingStack stk;   // stack_words / LP_BLOCK = ring size, a power of two (host)
-    stk.lds = lds_stack + threadIdx.x; stk.mask = stack_words / LP_BLOCK - 1u; stk.floor = 0u;
-    stk.threads = gridDim.x * LP_BLOCK; stk.overflow = stack_overflow + (size_t)blockIdx.x * LP_BLOCK + threadIdx.x;
     static_assert(LP_SHARDS <= LP_BLOCK && 256 % LP_SHARDS == 0, "block 0 books one shard per thread; 64-block grids hold whole waves per shard");
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t *counts = pb.counts + (size_t)iter * LP_SHARDS;
@@ -362,12 +354,15 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
 
     // this wave's share of the work
     const uint32_t wave = blockIdx.x * (LP_BLOCK / 64) + tid / 64;         // wave-uniform
-    const uint32_t shard = wave % LP_SHARDS;                                // the grid is a multiple of 64 blocks: whole waves per shard
+    const uint32_t wps = (gridDim.x * (LP_BLOCK / 64)) / LP_SHARDS;         // waves per shard (grid is a multiple of 64 blocks)
+    const uint32_t shard = wave % LP_SHARDS, j = wave / LP_SHARDS;
     const uint32_t cnt = counts[shard] * (MODE == 1 ? 2u : 1u);   // jobs
-    if (cnt == 0) return;
+    const uint32_t full_chunks = cnt / 64u;
+    uint32_t n_mine = (full_chunks > j) ? ((full_chunks - j - 1u) / wps + 1u) * 64u : 0u;
+    if ((cnt % 64u) && (full_chunks % wps) == j) n_mine += cnt % 64u;       // the partial last chunk
+    if (n_mine == 0) return;
     const size_t shard_base = (size_t)shard * pb.shard_cap;
-    uint32_t *cursor = pb.counts + (size_t)pb.counts_stride * (1u + MODE) + (size_t)iter * LP_SHARDS + shard;   // zeroed with the counts
-    bool exhausted = false;                                                 // the shard's queue has been handed out completely
+    uint32_t next_pos = 0;                                                  // position in this wave's private sequence
 
     const float eps = fp.pc.ray_epsilon;
     constexpr uint32_t REF_DONE = 0xFFFFFFFFu;
@@ -385,63 +380,20 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
     auto start_traversal = [&]() {
         inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         co = o; cd = d; cinv = inv_d;
-        sp = 0; blas_base = 0xFFFFFFFFu; stk.floor = 0u;
+        sp = 0; blas_base = 0xFFFFFFFFu;
         cur = sc.num_instances ? sc.tlas_root : REF_DONE;
         best.t = LP_F32_MAX; best.u = 0.0f; best.v = 0.0f; best.tri = 0u; best.inst = HIT_MISS;
     };
     auto pop = [&]() {
         if (sp == blas_base) { blas_base = 0xFFFFFFFFu; co = o; cd = d; cinv = inv_d; }
         if (sp == 0) { cur = REF_DONE; return; }
-        cur = stk.pop(sp);
+        sp--;
+        cur = lds_stack[sp * LP_BLOCK + tid];
     };
 
-    // Retire one finished traversal = one iteration of ray_skip_alpha_stochastically (bvh_custom.wgsl:154-180): either the
-    // hit goes out and the lane becomes free, or the surface is skipped and the ray restarts behind it.
-    auto retire = [&]() {
-        if (MODE == 1)
-        {
-            const bool hit = best.t != LP_F32_MAX;
-            const float4 rec = make_float4(hit ? best.t : 0.0f, hit ? best.u : 0.0f, hit ? best.v : 0.0f, __uint_as_float(hit ? best.inst : HIT_MISS));
-            if (TYPE == LUPIN_PATHTRACE_MIS && ray_k == 0) { pb.next_hit[slot] = rec; pb.next_tri[slot] = best.tri; }
-            else { pb.sh_hit1[slot] = rec; pb.sh_f1[slot].w = __uint_as_float(best.tri); }
-            active = false;
-            return;
-        }
-        const bool hit = best.t != LP_F32_MAX;
-        bool again = false;
-        if (hit)
-        {
-            total_dst += best.t;
-            if (sc.instances[best.inst].flags & 1u)
-            {
-                Surface sf = resolve_surface(sc, best.inst, best.tri, best.u, best.v);
-                float opacity = surface_opacity(sc, sf);
-                if (opacity < 1.0f && rnd(rng) >= opacity)
-                {
-                    o = add(o, scale(d, best.t));
-                    alpha_k++;
-                    again = alpha_k < 128u;   // MAX_OPACITY_BOUNCES (pathtracer.wgsl:1263)
-                }
-            }
-        }
-        if (again) start_traversal();
-        else
-        {
-            pb.hit[slot] = make_float4(total_dst, best.u, best.v, __uint_as_float(hit ? best.inst : HIT_MISS));
-            pb.hit_tri[slot] = best.tri;
-            if (rng != rng_in) pb.ori_rng[slot].w = __uint_as_float(rng);
-            active = false;
-        }
-    };
-
-    // Scheduling.  A lane is at an internal node (N), a TLAS leaf = instance entry (I), a triangle of a BLAS leaf (T), at
-    // the end of a traversal (F) or empty (E).  Round 1 executed, per round, the ONE phase most lanes waited for, so that
-    // every instruction ran with as many lanes as possible -- but the tracer is bound by the latency of its dependent
-    // fetches, not by instructions (PMC: waves wait on memory 62 % of their cycles, VALU busy a third of the time), and a
-    // node step then moved only 26 of 64 lanes.  Now every lane takes its OWN next step in every round: all three kinds of
-    // step begin with a 64-byte fetch, issued by one set of loads (Geo::fetch) so that they fly together, and the three
-    // pieces of arithmetic run one after the other under their lanes' masks.  More instructions per round, half the rounds.
-    // Finished lanes are retired, and empty ones refilled, in batches of `refill_min`.
+    // Phase scheduling: a lane is at an internal node (N), a TLAS leaf = instance entry (I), a triangle of a BLAS leaf (T),
+    // at the end of a traversal (F) or empty (E).  Every round the wave executes the ONE phase most of its lanes wait for
+    // (wave-uniform branch), so each instruction runs with as many lanes as possible; lanes of other phases just wait.
     for (;;)
     {
         const bool isN = active && !(cur & REF_LEAF);
@@ -450,33 +402,19 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
         const bool isI = isLeaf && blas_base == 0xFFFFFFFFu;
         const bool isT = isLeaf && !isI;
         const unsigned long long idle = __ballot(!active);
-        const uint32_t cE = (uint32_t)__popcll(idle), cF = (uint32_t)__popcll(__ballot(isF));
-        const uint32_t cN = (uint32_t)__popcll(__ballot(isN)), cT = (uint32_t)__popcll(__ballot(isT)), cI = (uint32_t)__popcll(__ballot(isI));
-        const bool stepping = (cN | cT | cI) != 0u;
-        // a kind of step runs when enough lanes wait for it to pay for its instructions, or when nothing else would run
-        const bool anyN = cN >= min(gate_n, cN + cT + cI) && cN != 0u;
-        const bool anyT = cT != 0u && (cT >= gate_t || cN < gate_n);
-        const bool anyI = cI != 0u && (cI >= gate_i || cN < gate_n);
-        if (COUNT && lane == 0u) tally[7]++;   // scheduling rounds of this wave
+        const uint32_t cE = (uint32_t)__popcll(idle);
+        const uint32_t cN = (uint32_t)__popcll(__ballot(isN)), cI = (uint32_t)__popcll(__ballot(isI));
+        const uint32_t cT = (uint32_t)__popcll(__ballot(isT)), cF = (uint32_t)__popcll(__ballot(isF));
 
-        if (cF && (cF + cE >= refill_min || !stepping))
+        if (cE >= refill_min && next_pos < n_mine)
         {
-            if (COUNT && lane == 0u) tally[5]++;   // retire rounds
-            if (isF) retire();
-            continue;
-        }
-        if (cE >= refill_min && !exhausted)
-        {
-            // ---- refill empty lanes: one atomic per wave takes the next cE entries of the shard's queue ----
-            if (COUNT && lane == 0u) tally[6]++;
+            // ---- refill empty lanes ----
             const uint32_t my_rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-            uint32_t first = 0;
-            if (lane == 0u) first = atomicAdd(cursor, cE);
-            first = __shfl(first, 0);
-            const uint32_t take = first < cnt ? min(cE, cnt - first) : 0u;
-            exhausted = first + cE >= cnt;
+            const uint32_t take = min(cE, n_mine - next_pos);
             const bool got = !active && my_rank < take;
-            const size_t q_index = shard_base + first + my_rank;
+            const uint32_t pos = next_pos + my_rank;
+            const size_t q_index = shard_base + (size_t)((pos / 64u) * wps + j) * 64u + pos % 64u;
+            next_pos += take;
             if (got && MODE == 0)
             {
                 slot = queue[q_index];
@@ -520,64 +458,106 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
             }
             continue;
         }
-        if (!stepping) break;   // nothing in flight and (see above) nothing left to fetch or retire
+        if (cE == 64u) break;   // nothing in flight and (see above) nothing left to fetch
 
-        // ---- one step per lane ----
-        if (COUNT && lane == 0u) tally[4]++;   // step rounds of this wave
-        Fetch64 f;
-        f.w0 = f.w1 = f.w2 = f.w3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if ((isN && anyN) || (isT && anyT) || (isI && anyI))
-            f = geo.fetch(isN ? 0u : (isT ? 1u : 2u), blas_base != 0xFFFFFFFFu, isN ? cur : (cur & ~REF_LEAF));
-        if (anyN)
+        if (cN >= cT && cN >= cI && cN >= cF)
         {
-            if (isN)
+            // ---- N: internal nodes of either level; keeps stepping while at least half of the voters are still at one ----
+            for (uint32_t r = 0;; r++)
             {
-                // internal node of either level (bvh_custom.wgsl:47-94, :234-283)
-                const NodeRegs nd = as_node(f);
-                float ld = slab_dst(co, cinv, nd.a.x, nd.a.y, nd.a.z, nd.a.w, nd.b.x, nd.b.y);
-                float rd = slab_dst(co, cinv, nd.b.z, nd.b.w, nd.c.x, nd.c.y, nd.c.z, nd.c.w);
-                bool left_first = ld <= rd;
-                bool push_l = ld < best.t, push_r = rd < best.t;
-                uint32_t near_ref = left_first ? nd.left : nd.right;
-                uint32_t far_ref = left_first ? nd.right : nd.left;
-                bool push_near = left_first ? push_l : push_r;
-                bool push_far = left_first ? push_r : push_l;
-                if (push_far) stk.push(sp, far_ref);
-                if (push_near) cur = near_ref; else pop();
+                const bool n = active && !(cur & REF_LEAF);
+                if (r > 0 && (r >= nsteps || (uint32_t)__popcll(__ballot(n)) * 2u < cN)) break;
+                if (n)
+                {
+                    const NodeRegs nd = geo.node(blas_base != 0xFFFFFFFFu, cur);
+                    float ld = slab_dst(co, cinv, nd.a.x, nd.a.y, nd.a.z, nd.a.w, nd.b.x, nd.b.y);
+                    float rd = slab_dst(co, cinv, nd.b.z, nd.b.w, nd.c.x, nd.c.y, nd.c.z, nd.c.w);
+                    bool left_first = ld <= rd;
+                    bool push_l = ld < best.t, push_r = rd < best.t;
+                    uint32_t near_ref = left_first ? nd.left : nd.right;
+                    uint32_t far_ref = left_first ? nd.right : nd.left;
+                    bool push_near = left_first ? push_l : push_r;
+                    bool push_far = left_first ? push_r : push_l;
+                    if (push_far) { lds_stack[sp * LP_BLOCK + tid] = far_ref; sp++; }
+                    if (push_near) cur = near_ref; else pop();
+                }
             }
         }
-        if (anyT)
+        else if (cT >= cI && cT >= cF)
         {
+            // ---- T: one triangle of a BLAS leaf, first-found wins ties (strict <) ----
             if (isT)
             {
-                // one triangle of a BLAS leaf, first-found wins ties (strict <)
                 const uint32_t ti = cur & ~REF_LEAF;
-                TriHit h = tri_dst(co, cd, xyz(f.w0), xyz(f.w1), xyz(f.w2), eps);
+                const TriVerts tv = geo.tri(ti);
+                TriHit h = tri_dst(co, cd, xyz(tv.v0), xyz(tv.v1), xyz(tv.v2), eps);
                 if (h.t < best.t) { best.t = h.t; best.u = h.u; best.v = h.v; best.tri = ti; best.inst = cur_inst; }
-                if (__float_as_uint(f.w0.w) & LEAF_END_BITS) pop(); else cur++;
+                if (__float_as_uint(tv.v0.w) & LEAF_END_BITS) pop(); else cur++;
             }
         }
-        if (anyI)
+        else if (cI >= cF)
         {
+            // ---- I: enter an instance (bvh_custom.wgsl:28-37) ----
             if (isI)
             {
-                // enter an instance (bvh_custom.wgsl:28-37)
                 cur_inst = cur & ~REF_LEAF;
-                const float4 r0 = f.w0, r1 = f.w1, r2 = f.w2;
-                const uint32_t blas_root = __float_as_uint(f.w3.x);
-                co = mk3(o.x * r0.x + o.y * r0.y + o.z * r0.z + 1.0f * r0.w,
-                         o.x * r1.x + o.y * r1.y + o.z * r1.z + 1.0f * r1.w,
-                         o.x * r2.x + o.y * r2.y + o.z * r2.z + 1.0f * r2.w);
-                cd = mk3(d.x * r0.x + d.y * r0.y + d.z * r0.z + 0.0f * r0.w,
-                         d.x * r1.x + d.y * r1.y + d.z * r1.z + 0.0f * r1.w,
-                         d.x * r2.x + d.y * r2.y + d.z * r2.z + 0.0f * r2.w);
-                if (!(blas_root & REF_LEAF)) cinv = mk3(1.0f / cd.x, 1.0f / cd.y, 1.0f / cd.z);
+                const InstanceDev in = geo.inst(cur_inst);
+                co = mk3(o.x * in.r0.x + o.y * in.r0.y + o.z * in.r0.z + 1.0f * in.r0.w,
+                         o.x * in.r1.x + o.y * in.r1.y + o.z * in.r1.z + 1.0f * in.r1.w,
+                         o.x * in.r2.x + o.y * in.r2.y + o.z * in.r2.z + 1.0f * in.r2.w);
+                cd = mk3(d.x * in.r0.x + d.y * in.r0.y + d.z * in.r0.z + 0.0f * in.r0.w,
+                         d.x * in.r1.x + d.y * in.r1.y + d.z * in.r1.z + 0.0f * in.r1.w,
+                         d.x * in.r2.x + d.y * in.r2.y + d.z * in.r2.z + 0.0f * in.r2.w);
+                if (!(in.blas_root & REF_LEAF)) cinv = mk3(1.0f / cd.x, 1.0f / cd.y, 1.0f / cd.z);
                 blas_base = sp;
-                cur = blas_root;
+                cur = in.blas_root;
+            }
+        }
+        else
+        {
+            // ---- F: end of a traversal = one iteration of ray_skip_alpha_stochastically (bvh_custom.wgsl:154-180) ----
+            if (isF && MODE == 1)
+            {
+                const bool hit = best.t != LP_F32_MAX;
+                const float4 rec = make_float4(hit ? best.t : 0.0f, hit ? best.u : 0.0f, hit ? best.v : 0.0f, __uint_as_float(hit ? best.inst : HIT_MISS));
+                if (TYPE == LUPIN_PATHTRACE_MIS && ray_k == 0) { pb.next_hit[slot] = rec; pb.next_tri[slot] = best.tri; }
+                else { pb.sh_hit1[slot] = rec; pb.sh_f1[slot].w = __uint_as_float(best.tri); }
+                active = false;
+            }
+            if (isF && MODE == 0)
+            {
+                const bool hit = best.t != LP_F32_MAX;
+                bool again = false;
+                if (hit)
+                {
+                    total_dst += best.t;
+                    if (sc.instances[best.inst].flags & 1u)
+                    {
+                        Surface sf = resolve_surface(sc, best.inst, best.tri, best.u, best.v);
+                        float opacity = surface_opacity(sc, sf);
+                        if (opacity < 1.0f && rnd(rng) >= opacity)
+                        {
+                            o = add(o, scale(d, best.t));
+                            alpha_k++;
+                            again = alpha_k < 128u;   // MAX_OPACITY_BOUNCES (pathtracer.wgsl:1263)
+                        }
+                    }
+                }
+                if (again)
+                {
+                    start_traversal();
+                }
+                else
+                {
+                    pb.hit[slot] = make_float4(total_dst, best.u, best.v, __uint_as_float(hit ? best.inst : HIT_MISS));
+                    pb.hit_tri[slot] = best.tri;
+                    if (rng != rng_in) pb.ori_rng[slot].w = __uint_as_float(rng);
+                    active = false;
+                }
             }
         }
     }
-    if (COUNT) tally_flush(tally, work + 8 * MODE);   // the loop ends wave-uniformly: all lanes are here
+    if (COUNT) tally_flush(tally, work + 3 * MODE);   // the loop ends wave-uniformly: all lanes are here
 }
 
 // clamp_radiance (pathtracer.wgsl:1774-1783)
@@ -1109,14 +1089,8 @@ __global__ void __launch_bounds__(LP_BLOCK) k_resolve(FrameParams fp, PathBuffer
 // device-to-device copy: the measured HBM peak bench.py reports next to the nominal one
 __global__ void __launch_bounds__(LP_BLOCK) k_copy_bw(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n)
 {
-    const size_t stride = (size_t)gridDim.x * LP_BLOCK;
-    size_t i = (size_t)blockIdx.x * LP_BLOCK + threadIdx.x;
-    for (; i + 3 * stride < n; i += 4 * stride)   // four independent 16-byte loads in flight per lane
-    {
-        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
-    }
-    for (; i < n; i += stride) dst[i] = src[i];
+    const size_t i = (size_t)blockIdx.x * LP_BLOCK + threadIdx.x;
+    if (i < n) dst[i] = src[i];
 }
 
 // pathtrace_falsecolor_main (pathtracer.wgsl:296-452): G-buffer style visualisations, one thread per pixel, no bounces.
