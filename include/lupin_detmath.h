@@ -8,16 +8,21 @@
  * and an absolute 2^-11 for sin/cos).  A path tracer branches on these values
  * (`rnl < fresnel`, Russian roulette), so two implementations only follow the same paths on the
  * same RNG stream if their transcendentals agree bit for bit.  These functions use nothing but
- * +,-,*,/ ,sqrt, rint and conversions in double precision (all correctly rounded on x86-64 and
- * on gfx950), no fused contraction, so host and device produce identical bits.  Accuracy:
- * |error| < 1e-11 relative before the final rounding, i.e. correctly rounded f32 except for
- * astronomically rare ties -- far inside the precision WGSL guarantees.
+ * +,-,*,/ ,sqrt, rint, conversions and EXPLICIT fused multiply-adds (LPM_FMA = fma(), one rounding, in
+ * the polynomial steps) in double precision -- all correctly rounded on x86-64 and on gfx950 -- and no
+ * implicit contraction, so host and device produce identical bits.  Accuracy: |error| < 1e-11 relative
+ * before the final rounding, i.e. correctly rounded f32 except for astronomically rare ties -- far
+ * inside the precision WGSL guarantees.  (Round 1 evaluated the polynomials as separate multiplies and
+ * adds and carried them to 1e-15: on the GPU these double-precision steps were 15 % of the shading
+ * kernel's vector instructions, at half rate; fused steps and series cut to what an f32 result can
+ * show make them about 2.5 times cheaper.)
  *
  * Both the CPU oracle (oracle/) and the HIP kernels include this header; it is part of the
  * arithmetic specification, not of either implementation.  tests/test_detmath.py pins it
  * against numpy's float64 libm.
  *
- * Compile with -ffp-contract=off (hipcc defaults to fast contraction!).
+ * Compile with -ffp-contract=off (hipcc defaults to fast contraction!); the CPU side wants -mfma so that
+ * fma() is one instruction (without it the C library's correctly rounded fma() gives the same bits, slowly).
  */
 #ifndef LUPIN_DETMATH_H
 #define LUPIN_DETMATH_H
@@ -31,6 +36,8 @@
 #define LPM_FN static inline
 #endif
 
+#define LPM_FMA(a, b, c) __builtin_fma((a), (b), (c))
+
 LPM_FN uint64_t lpm_d2u(double x) { uint64_t u; __builtin_memcpy(&u, &x, 8); return u; }
 LPM_FN double   lpm_u2d(uint64_t u) { double x; __builtin_memcpy(&x, &u, 8); return x; }
 LPM_FN double   lpm_nan(void) { return lpm_u2d(0x7FF8000000000000ull); }
@@ -42,7 +49,7 @@ LPM_FN double   lpm_pow2i(int e) { return lpm_u2d((uint64_t)(e + 1023) << 52); }
 #define LPM_PIO2    1.57079632679489661923
 #define LPM_PIO4    0.78539816339744830962
 
-/* sin and cos of x (double in, double out, |err| < 1e-15 for |x| < 1e5) */
+/* sin and cos of x (double in, double out, |err| < 1e-13 for |x| < 1e5) */
 LPM_FN void lpm_sincos_d(double x, double *s_out, double *c_out)
 {
     double ax = fabs(x);
@@ -52,29 +59,27 @@ LPM_FN void lpm_sincos_d(double x, double *s_out, double *c_out)
     const double PIO2_HI = 1.57079632673412561417e+00;  /* first 33 bits of pi/2 */
     const double PIO2_LO = 6.07710050650619224932e-11;  /* pi/2 - PIO2_HI */
     double kd = rint(x * TWO_OVER_PI);
-    double r = (x - kd * PIO2_HI) - kd * PIO2_LO;
+    double r = LPM_FMA(-kd, PIO2_LO, LPM_FMA(-kd, PIO2_HI, x));
     long long k = (long long)kd;
     int q = (int)(k & 3);
 
     double r2 = r * r;
-    /* sin r = r + r^3 * S(r^2), Taylor through r^15 */
-    double S = -7.6471637318198164759e-13;             /* -1/15! */
-    S = S * r2 + 1.6059043836821614599e-10;            /*  1/13! */
-    S = S * r2 - 2.5052108385441718775e-08;            /* -1/11! */
-    S = S * r2 + 2.7557319223985890653e-06;            /*  1/9!  */
-    S = S * r2 - 1.9841269841269841270e-04;            /* -1/7!  */
-    S = S * r2 + 8.3333333333333333333e-03;            /*  1/5!  */
-    S = S * r2 - 1.6666666666666666667e-01;            /* -1/3!  */
-    double sr = r + r * r2 * S;
-    /* cos r = 1 - r^2/2 + r^4 * C(r^2), Taylor through r^16 */
-    double C = 4.7794773323873852974e-14;              /*  1/16! */
-    C = C * r2 - 1.1470745597729724714e-11;            /* -1/14! */
-    C = C * r2 + 2.0876756987868098979e-09;            /*  1/12! */
-    C = C * r2 - 2.7557319223985890653e-07;            /* -1/10! */
-    C = C * r2 + 2.4801587301587301587e-05;            /*  1/8!  */
-    C = C * r2 - 1.3888888888888888889e-03;            /* -1/6!  */
-    C = C * r2 + 4.1666666666666666667e-02;            /*  1/4!  */
-    double cr = (1.0 - 0.5 * r2) + r2 * r2 * C;
+    /* |r| <= pi/4.  sin r = r + r^3 * S(r^2), Taylor through r^13 (next term < 2e-14 relative) */
+    double S = 1.6059043836821614599e-10;              /*  1/13! */
+    S = LPM_FMA(S, r2, -2.5052108385441718775e-08);    /* -1/11! */
+    S = LPM_FMA(S, r2, 2.7557319223985890653e-06);     /*  1/9!  */
+    S = LPM_FMA(S, r2, -1.9841269841269841270e-04);    /* -1/7!  */
+    S = LPM_FMA(S, r2, 8.3333333333333333333e-03);     /*  1/5!  */
+    S = LPM_FMA(S, r2, -1.6666666666666666667e-01);    /* -1/3!  */
+    double sr = LPM_FMA(r * r2, S, r);
+    /* cos r = 1 - r^2/2 + r^4 * C(r^2), Taylor through r^14 (next term < 1e-15) */
+    double C = -1.1470745597729724714e-11;             /* -1/14! */
+    C = LPM_FMA(C, r2, 2.0876756987868098979e-09);     /*  1/12! */
+    C = LPM_FMA(C, r2, -2.7557319223985890653e-07);    /* -1/10! */
+    C = LPM_FMA(C, r2, 2.4801587301587301587e-05);     /*  1/8!  */
+    C = LPM_FMA(C, r2, -1.3888888888888888889e-03);    /* -1/6!  */
+    C = LPM_FMA(C, r2, 4.1666666666666666667e-02);     /*  1/4!  */
+    double cr = LPM_FMA(r2 * r2, C, LPM_FMA(-0.5, r2, 1.0));
 
     double s, c;
     if (q == 0)      { s = sr;  c = cr;  }
@@ -95,22 +100,22 @@ LPM_FN double lpm_atan_d(double x)
     else if (t > TP8) { base = LPM_PIO4; r = (t - 1.0) / (t + 1.0); }
     else              { base = 0.0;      r = t; }
     double z = r * r;
-    /* sum_{n=0}^{13} (-1)^n z^n / (2n+1), Horner */
+    /* |r| <= tan(pi/8): sum_{n=0}^{13} (-1)^n z^n / (2n+1), Horner (next term < 4e-13 relative) */
     double p = -1.0 / 27.0;
-    p = p * z + 1.0 / 25.0;
-    p = p * z - 1.0 / 23.0;
-    p = p * z + 1.0 / 21.0;
-    p = p * z - 1.0 / 19.0;
-    p = p * z + 1.0 / 17.0;
-    p = p * z - 1.0 / 15.0;
-    p = p * z + 1.0 / 13.0;
-    p = p * z - 1.0 / 11.0;
-    p = p * z + 1.0 / 9.0;
-    p = p * z - 1.0 / 7.0;
-    p = p * z + 1.0 / 5.0;
-    p = p * z - 1.0 / 3.0;
-    p = p * z + 1.0;
-    double a = base + r * p;
+    p = LPM_FMA(p, z, 1.0 / 25.0);
+    p = LPM_FMA(p, z, -1.0 / 23.0);
+    p = LPM_FMA(p, z, 1.0 / 21.0);
+    p = LPM_FMA(p, z, -1.0 / 19.0);
+    p = LPM_FMA(p, z, 1.0 / 17.0);
+    p = LPM_FMA(p, z, -1.0 / 15.0);
+    p = LPM_FMA(p, z, 1.0 / 13.0);
+    p = LPM_FMA(p, z, -1.0 / 11.0);
+    p = LPM_FMA(p, z, 1.0 / 9.0);
+    p = LPM_FMA(p, z, -1.0 / 7.0);
+    p = LPM_FMA(p, z, 1.0 / 5.0);
+    p = LPM_FMA(p, z, -1.0 / 3.0);
+    p = LPM_FMA(p, z, 1.0);
+    double a = LPM_FMA(r, p, base);
     return (x < 0.0) ? -a : a;
 }
 
@@ -133,7 +138,7 @@ LPM_FN double lpm_acos_d(double x)
     return lpm_atan2_d(sqrt((1.0 - x) * (1.0 + x)), x);
 }
 
-/* exp(x), relative error < 1e-15 */
+/* exp(x), relative error < 1e-12 */
 LPM_FN double lpm_exp_d(double x)
 {
     if (x != x) return x;
@@ -143,28 +148,26 @@ LPM_FN double lpm_exp_d(double x)
     const double LN2_HI = 6.93147180369123816490e-01;
     const double LN2_LO = 1.90821492927058770002e-10;
     double kd = rint(x * LOG2E);
-    double r = (x - kd * LN2_HI) - kd * LN2_LO;
+    double r = LPM_FMA(-kd, LN2_LO, LPM_FMA(-kd, LN2_HI, x));
     int k = (int)kd;
-    double p = 1.0 / 6227020800.0;          /* 1/13! */
-    p = p * r + 1.0 / 479001600.0;          /* 1/12! */
-    p = p * r + 1.0 / 39916800.0;
-    p = p * r + 1.0 / 3628800.0;
-    p = p * r + 1.0 / 362880.0;
-    p = p * r + 1.0 / 40320.0;
-    p = p * r + 1.0 / 5040.0;
-    p = p * r + 1.0 / 720.0;
-    p = p * r + 1.0 / 120.0;
-    p = p * r + 1.0 / 24.0;
-    p = p * r + 1.0 / 6.0;
-    p = p * r + 0.5;
-    p = p * r + 1.0;
-    p = p * r + 1.0;
+    /* |r| <= ln2 / 2: Taylor through r^10 (next term < 3e-13) */
+    double p = 1.0 / 3628800.0;             /* 1/10! */
+    p = LPM_FMA(p, r, 1.0 / 362880.0);
+    p = LPM_FMA(p, r, 1.0 / 40320.0);
+    p = LPM_FMA(p, r, 1.0 / 5040.0);
+    p = LPM_FMA(p, r, 1.0 / 720.0);
+    p = LPM_FMA(p, r, 1.0 / 120.0);
+    p = LPM_FMA(p, r, 1.0 / 24.0);
+    p = LPM_FMA(p, r, 1.0 / 6.0);
+    p = LPM_FMA(p, r, 0.5);
+    p = LPM_FMA(p, r, 1.0);
+    p = LPM_FMA(p, r, 1.0);
     int k1 = k / 2;
     int k2 = k - k1;
     return (p * lpm_pow2i(k1)) * lpm_pow2i(k2);
 }
 
-/* natural log, |err| < 1e-15 relative */
+/* natural log, |err| < 1e-14 relative */
 LPM_FN double lpm_log_d(double x)
 {
     if (x != x) return x;
@@ -183,22 +186,21 @@ LPM_FN double lpm_log_d(double x)
     if (m > 1.41421356237309504880) { m = m * 0.5; e += 1; }
     double s = (m - 1.0) / (m + 1.0);
     double z = s * s;
-    double p = 1.0 / 21.0;
-    p = p * z + 1.0 / 19.0;
-    p = p * z + 1.0 / 17.0;
-    p = p * z + 1.0 / 15.0;
-    p = p * z + 1.0 / 13.0;
-    p = p * z + 1.0 / 11.0;
-    p = p * z + 1.0 / 9.0;
-    p = p * z + 1.0 / 7.0;
-    p = p * z + 1.0 / 5.0;
-    p = p * z + 1.0 / 3.0;
-    p = p * z + 1.0;
+    /* |s| <= 0.1716: 2 s sum_{n=0}^{8} z^n / (2n+1) (next term < 2e-16 relative) */
+    double p = 1.0 / 17.0;
+    p = LPM_FMA(p, z, 1.0 / 15.0);
+    p = LPM_FMA(p, z, 1.0 / 13.0);
+    p = LPM_FMA(p, z, 1.0 / 11.0);
+    p = LPM_FMA(p, z, 1.0 / 9.0);
+    p = LPM_FMA(p, z, 1.0 / 7.0);
+    p = LPM_FMA(p, z, 1.0 / 5.0);
+    p = LPM_FMA(p, z, 1.0 / 3.0);
+    p = LPM_FMA(p, z, 1.0);
     double logm = 2.0 * s * p;
     const double LN2_HI = 6.93147180369123816490e-01;
     const double LN2_LO = 1.90821492927058770002e-10;
     double ed = (double)e;
-    return ed * LN2_HI + (ed * LN2_LO + logm);
+    return LPM_FMA(ed, LN2_HI, LPM_FMA(ed, LN2_LO, logm));
 }
 
 /* ---- f32 entry points: one rounding at the end ---- */

@@ -67,6 +67,7 @@ struct LupinContext
     int last_lane = -1;
     hipEvent_t marker = nullptr;
     bool timing = false;
+    bool debug_sync = false;        // LUPIN_DEBUG_SYNC=1: synchronise and report after every stage launch (fault localisation)
     bool counting = false;          // lupin_hip_stats_reset(ctx, 2): the tracing kernels run their work-counting instantiation
     int accum_mode = 0;             // LUPIN_ACCUM_F16_RUNNING_AVERAGE | LUPIN_ACCUM_F32
     int runtime_version = 0;        // hipRuntimeGetVersion of the libamdhip64 this process bound
@@ -257,6 +258,11 @@ static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *sc
             hipLaunchKernelGGL((k_extend<TYPE, LDSGEO, false, false>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words, work);
     }
     if (ctx->timing) hipEventRecord(e1, st);
+    if (ctx->debug_sync)
+    {
+        hipError_t de = hipStreamSynchronize(st);
+        fprintf(stderr, "[lupin] iteration %u type %d: extend done: %s\n", iter, TYPE, hipGetErrorString(de)); fflush(stderr);
+    }
     if (scene->simple_matte && ctx->specialize_simple)
         hipLaunchKernelGGL((k_shade<TYPE, LDSGEO, true>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
     else
@@ -276,6 +282,12 @@ static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *sc
         }
         else
             hipLaunchKernelGGL((k_shadow<TYPE, LDSGEO, false>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, stack_words);
+    }
+    if (ctx->debug_sync)
+    {
+        fprintf(stderr, "[lupin] iteration %u type %d: stages launched, syncing\n", iter, TYPE); fflush(stderr);
+        hipError_t de = hipStreamSynchronize(st);
+        fprintf(stderr, "[lupin] iteration %u: %s\n", iter, hipGetErrorString(de)); fflush(stderr);
     }
     if (ctx->timing)
     {
@@ -405,6 +417,8 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
         if (bpc) ctx->blocks_per_cu_override = std::max(0, atoi(bpc));
         ctx->num_cus = (uint32_t)prop.multiProcessorCount;
     }
+    const char *dbs = getenv("LUPIN_DEBUG_SYNC");
+    ctx->debug_sync = dbs && strcmp(dbs, "0") != 0;
     const char *ssh = getenv("LUPIN_SIMPLE_SHADE");
     if (ssh && strcmp(ssh, "0") == 0) ctx->specialize_simple = false;
     const char *gr = getenv("LUPIN_GRAPH");

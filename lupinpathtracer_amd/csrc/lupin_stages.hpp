@@ -591,8 +591,12 @@ struct PathRegs
 // path continues with (ori, dir) set for the next bounce, false on `break`.
 // TYPE 0: pathtrace_standard (:588-733)   1: pathtrace_mis (:737-933)
 //      2: pathtrace_naive (:942-1059)     3: pathtrace_direct (:1062-1245)
+// Always inlined: as a real device function (the compiler's choice for the Direct integrator once its callees shrank) the
+// call passes SceneDev / PathRegs / ShadowRays through scratch memory, which is slow ("outlined helpers") and,
+// on ROCm 7.2, faulted: pointers of the scratch copy of SceneDev read back as material data (address = the bits of
+// {roughness, metallic}) in k_shade<Direct> on materials4.
 template <int TYPE, typename Geo, bool SIMPLE = false>
-__device__ bool integrate_vertex(const Geo &geo, const SceneDev &sc, uint32_t *stack, const FrameParams &fp, PathRegs &p,
+__device__ __forceinline__ bool integrate_vertex(const Geo &geo, const SceneDev &sc, uint32_t *stack, const FrameParams &fp, PathRegs &p,
                                  float4 hitrec, uint32_t hit_tri, ShadowRays &sh)
 {
     const float eps = fp.pc.ray_epsilon;

@@ -4,7 +4,7 @@
 set -e
 ASAN=$(gcc -print-file-name=libasan.so); UBSAN=$(gcc -print-file-name=libubsan.so)
 SAN="-fsanitize=address,undefined -fno-omit-frame-pointer -O1 -g -std=c++17"
-g++ $SAN -fPIC -ffp-contract=off -fno-fast-math -fopenmp -shared -o /tmp/liblupin_oracle_asan.so oracle/lupin_oracle.cpp
+g++ $SAN -fPIC -ffp-contract=off -fno-fast-math -mfma -fopenmp -shared -o /tmp/liblupin_oracle_asan.so oracle/lupin_oracle.cpp
 g++ $SAN -fPIC -Iinclude -shared lupinpathtracer_amd/csrc/builders.cpp -o /tmp/libbuilders_asan.so
 g++ $SAN -Iinclude tests/loader_dump.cpp -Llupinpathtracer_amd -llupin_hip -L/opt/rocm/lib -Wl,-rpath,$PWD/lupinpathtracer_amd -Wl,-rpath,/opt/rocm/lib -lz -o /tmp/loader_dump_asan
 export ASAN_OPTIONS=detect_leaks=0
