@@ -18,6 +18,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <array>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -97,6 +98,9 @@ class Device   // the reference's (wgpu::Device, wgpu::Queue) pair
     Device &operator=(const Device &) = delete;
     LupinContext *raw() const { return ctx_; }
     void poll_wait() const { check(lupin_hip_sync(ctx_)); }   // device.poll(wait_indefinitely)
+    // pathtracer.wgsl:275-289 re-quantises the running mean to f16 every frame (default, LUPIN_ACCUM_F16_RUNNING_AVERAGE);
+    // LUPIN_ACCUM_F32 runs the same recurrence on an f32 shadow of each texture and stores the rounded f16 view
+    void set_accumulation_mode(int mode) const { check(lupin_hip_set_accumulation_mode(ctx_, mode)); }
   private:
     LupinContext *ctx_ = nullptr;
 };
@@ -128,6 +132,12 @@ class TextureRef   // a borrowed Rgba16Float render target (wgpu::Texture)
     {
         std::vector<uint16_t> px((size_t)width() * height() * 4);
         check(lupin_hip_texture_download_rgba16f(t_, px.data()));
+        return px;
+    }
+    std::vector<float> download_f32() const   // the f32 accumulator (LUPIN_ACCUM_F32 frames only)
+    {
+        std::vector<float> px((size_t)width() * height() * 4);
+        check(lupin_hip_texture_download_rgba32f(t_, px.data()));
         return px;
     }
   private:
@@ -325,6 +335,57 @@ inline void pathtrace_scene(const Device &d, const PathtraceResources &res, cons
     LupinPathtraceDesc c{};
     detail::fill_desc(desc, ap, tp, c);
     check(lupin_hip_pathtrace_scene(d.raw(), res.raw(), scene.raw(), render_target.raw(), (uint32_t)type, &c));
+}
+
+// ---- multi-GPU extension (no counterpart in the reference, which is single-device; tile mathematics renderer.rs:807-829) ----
+
+// All tiles of the frame owned by `rank` (include/lupin_tiles.h) in one launch; desc.tile_params is ignored.
+inline void pathtrace_scene_tiles(const Device &d, const PathtraceResources &res, const Scene &scene, TextureRef render_target,
+                                  PathtraceType type, const PathtraceDesc &desc, uint32_t tile_size, uint32_t rank, uint32_t world)
+{
+    LupinAccumulationParams ap{};
+    LupinTileParams tp{};
+    LupinPathtraceDesc c{};
+    detail::fill_desc(desc, ap, tp, c);
+    check(lupin_hip_pathtrace_scene_tiles(d.raw(), res.raw(), scene.raw(), render_target.raw(), (uint32_t)type, &c, tile_size, rank, world));
+}
+
+// RCCL communicator of one Device; gather_framebuffer = pack own tiles -> ncclAllGather -> scatter the others' tiles.
+class Comm
+{
+  public:
+    static std::array<uint8_t, LUPIN_COMM_ID_BYTES> unique_id() { std::array<uint8_t, LUPIN_COMM_ID_BYTES> id{}; check(lupin_hip_comm_get_unique_id(id.data())); return id; }
+    Comm(const Device &d, const std::array<uint8_t, LUPIN_COMM_ID_BYTES> &id, uint32_t rank, uint32_t world) { check(lupin_hip_comm_init_rank(d.raw(), id.data(), rank, world, &c_)); }
+    explicit Comm(LupinComm *adopted) : c_(adopted) {}
+    Comm(Comm &&o) noexcept : c_(o.c_) { o.c_ = nullptr; }
+    Comm(const Comm &) = delete;
+    ~Comm() { if (c_) lupin_hip_comm_destroy(c_); }
+    // one process driving several devices (one context per GPU)
+    static std::vector<Comm> init_all(const std::vector<const Device *> &devices)
+    {
+        std::vector<LupinContext *> ctxs;
+        for (const Device *d : devices) ctxs.push_back(d->raw());
+        std::vector<LupinComm *> raw(devices.size(), nullptr);
+        check(lupin_hip_comm_init_all(ctxs.data(), (uint32_t)ctxs.size(), raw.data()));
+        std::vector<Comm> out;
+        for (LupinComm *c : raw) out.emplace_back(c);
+        return out;
+    }
+    void gather_framebuffer(TextureRef tex, uint32_t tile_size) const { check(lupin_hip_gather_framebuffer(c_, tex.raw(), tile_size)); }
+    void barrier() const { check(lupin_hip_comm_barrier(c_)); }
+    uint32_t rank() const { return lupin_hip_comm_rank(c_); }
+    uint32_t world() const { return lupin_hip_comm_world(c_); }
+    LupinComm *raw() const { return c_; }
+  private:
+    LupinComm *c_ = nullptr;
+};
+inline void gather_framebuffer_all(const std::vector<Comm> &comms, const std::vector<TextureRef> &texs, uint32_t tile_size)
+{
+    std::vector<LupinComm *> c;
+    std::vector<LupinTexture *> t;
+    for (const Comm &x : comms) c.push_back(x.raw());
+    for (const TextureRef &x : texs) t.push_back(x.raw());
+    check(lupin_hip_gather_framebuffer_all(c.data(), t.data(), (uint32_t)c.size(), tile_size));
 }
 
 // lp::pathtrace_scene_falsecolor (renderer.rs:872-948)

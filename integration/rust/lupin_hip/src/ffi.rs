@@ -4,7 +4,7 @@
 use std::os::raw::{c_char, c_int, c_void};
 
 macro_rules! opaque { ($($n:ident),*) => { $(#[repr(C)] pub struct $n { _p: [u8; 0] })* } }
-opaque!(LupinContext, LupinPathtraceResources, LupinScene, LupinTexture, LupinDoubleBufferedTexture);
+opaque!(LupinContext, LupinPathtraceResources, LupinScene, LupinTexture, LupinDoubleBufferedTexture, LupinComm);
 
 pub const LUPIN_OK: c_int = 0;
 pub const LUPIN_SENTINEL_IDX: u32 = 0xFFFF_FFFF;
@@ -91,6 +91,21 @@ extern "C" {
     pub fn lupin_hip_pathtrace_scene_tiles(ctx: *mut LupinContext, res: *const LupinPathtraceResources, scene: *const LupinScene,
                                            target: *mut LupinTexture, pathtrace_type: u32, desc: *const LupinPathtraceDesc,
                                            tile_size: u32, rank: u32, world: u32) -> c_int;
+    // multi-GPU: the one exchange step (RCCL all-gather of tile payloads over xGMI) and its communicators
+    pub fn lupin_hip_comm_get_unique_id(out_id: *mut u8) -> c_int;
+    pub fn lupin_hip_comm_init_rank(ctx: *mut LupinContext, id: *const u8, rank: u32, world: u32, out: *mut *mut LupinComm) -> c_int;
+    pub fn lupin_hip_comm_init_all(ctxs: *const *mut LupinContext, n: u32, out_comms: *mut *mut LupinComm) -> c_int;
+    pub fn lupin_hip_comm_from_nccl(ctx: *mut LupinContext, nccl_comm: *mut c_void, rank: u32, world: u32, out: *mut *mut LupinComm) -> c_int;
+    pub fn lupin_hip_comm_destroy(comm: *mut LupinComm);
+    pub fn lupin_hip_comm_rank(comm: *const LupinComm) -> u32;
+    pub fn lupin_hip_comm_world(comm: *const LupinComm) -> u32;
+    pub fn lupin_hip_gather_framebuffer(comm: *mut LupinComm, tex: *mut LupinTexture, tile_size: u32) -> c_int;
+    pub fn lupin_hip_gather_framebuffer_all(comms: *const *mut LupinComm, texs: *const *mut LupinTexture, n: u32, tile_size: u32) -> c_int;
+    pub fn lupin_hip_comm_barrier(comm: *mut LupinComm) -> c_int;
+    pub fn lupin_hip_comm_allreduce_f64(comm: *mut LupinComm, inout: *mut f64, n: u32, op: u32) -> c_int;
+    // accumulation mode (f16 running average = reference, or f32 accumulator) and its readback
+    pub fn lupin_hip_set_accumulation_mode(ctx: *mut LupinContext, mode: c_int) -> c_int;
+    pub fn lupin_hip_texture_download_rgba32f(tex: *const LupinTexture, out_pixels: *mut f32) -> c_int;
     pub fn lupin_hip_tonemap_and_fit_aspect(ctx: *mut LupinContext, src: *const LupinTexture, dst_rgba8: *mut u8, w: u32, h: u32,
                                             desc: *const LupinTonemapDesc) -> c_int;
     // host-side builders with the results of lupin/src/data_structures.rs
