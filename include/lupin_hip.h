@@ -556,6 +556,15 @@ uint64_t lupin_hip_lbvh_node_count(uint32_t num_tris);
 int64_t lupin_hip_build_bvh_device(LupinContext *ctx, const float *verts_pos4, uint32_t num_verts, uint32_t *indices,
                                    uint32_t num_indices, LupinBvhNode *out_nodes, uint64_t out_capacity);
 
+/* The reference's own BLAS builder run on the device (csrc/sahbvh.hip): level-synchronous binned SAH that reproduces
+ * lp::build_bvh's decisions (data_structures.rs:196-475: 5 bins per axis, half-area x count cost, centroid[axis] <= pos
+ * partition, depth cap) from min / max / count reductions, so every node's box, split plane and triangle SET equals
+ * lupin_build_bvh's bit for bit.  Only bookkeeping differs: nodes are numbered level by level and both sides of a
+ * partition keep their input order.  Same signature and return value as lupin_build_bvh (out_nodes must not be NULL;
+ * 2 * triangles - 1 nodes always suffice).  Synchronous. */
+int64_t lupin_hip_build_bvh_sah_device(LupinContext *ctx, const float *verts_pos4, uint32_t num_verts, uint32_t *indices,
+                                       uint32_t num_indices, LupinBvhNode *out_nodes, uint64_t out_capacity);
+
 /* build_bvh (data_structures.rs:196-235): reorders `indices` in place; returns node count or <0.
  * out_nodes may be NULL to query the count (indices untouched in that case). */
 int64_t lupin_build_bvh(const float *verts_pos4, uint32_t num_verts, uint32_t *indices,

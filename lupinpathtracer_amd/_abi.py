@@ -189,6 +189,7 @@ SYMBOLS = [
     ("lupin_hip_lbvh_depth", _U32, [_U32]),
     ("lupin_hip_lbvh_node_count", C.c_uint64, [_U32]),
     ("lupin_hip_build_bvh_device", C.c_int64, [_P, _P, _U32, _P, _U32, _P, C.c_uint64]),
+    ("lupin_hip_build_bvh_sah_device", C.c_int64, [_P, _P, _U32, _P, _U32, _P, C.c_uint64]),
     ("lupin_hip_pack_tiles", C.c_int, [_P, _P, _U32, _U32, _U32, _P, C.POINTER(C.c_uint64)]),
     ("lupin_hip_unpack_tiles", C.c_int, [_P, _P, _U32, _U32, _U32, _P]),
     ("lupin_hip_unpack_gathered_tiles", C.c_int, [_P, _P, _U32, _U32, _U32, _P, C.c_uint64]),

@@ -458,6 +458,19 @@ def build_bvh_device(ctx, verts_pos, indices):
     return nodes, idx
 
 
+def build_bvh_sah_device(ctx, verts_pos, indices):
+    """lp::build_bvh (data_structures.rs:196-235) run on the device (csrc/sahbvh.hip): the same tree as build_bvh -- same
+    boxes, split planes and triangle set per node -- numbered level by level.  Returns (nodes, reordered indices)."""
+    verts = np.ascontiguousarray(verts_pos, np.float32).reshape(-1, 4)
+    idx = np.ascontiguousarray(indices, np.uint32).copy()
+    cap = max(2 * (len(idx) // 3) - 1, 1)
+    nodes = np.zeros(cap, BVH_NODE_DTYPE)
+    n = lib().lupin_hip_build_bvh_sah_device(ctx.handle, ptr(verts), len(verts), ptr(idx), len(idx), ptr(nodes), cap)
+    if n < 0:
+        check(int(n))
+    return nodes[:n].copy(), idx
+
+
 def build_tlas(instances, model_aabbs):
     """lp::build_tlas (data_structures.rs:545-641). model_aabbs: (num_meshes, 6)."""
     inst = np.ascontiguousarray(instances)
@@ -553,13 +566,14 @@ def build_accel_structures_and_upload(ctx, scene: SceneCPU, textures: List[Textu
 
     ctx may be None: the host-side preprocessing still runs and `Scene.desc` is usable (CPU-only
     tests feed it to the oracle); nothing is uploaded then.
-    blas_builder: "sah" = the reference's CPU builder (lupin_build_bvh), "lbvh" = the device builder
+    blas_builder: "sah" = the reference's CPU builder (lupin_build_bvh), "sah_device" = the same tree built on the GPU
+    (build_bvh_sah_device; meshes with at least 64 triangles), "lbvh" = the Morton-order device builder
     (build_bvh_device; meshes with at least 64 triangles, smaller ones keep the SAH builder); a callable
     (verts (N,4), indices) -> (nodes, reordered indices) plugs in any other builder that emits the reference's node format.
     """
-    if not callable(blas_builder) and blas_builder not in ("sah", "lbvh"):
-        raise ValueError("blas_builder must be 'sah', 'lbvh' or a callable (verts, indices) -> (nodes, reordered indices)")
-    if blas_builder == "lbvh" and ctx is None:
+    if not callable(blas_builder) and blas_builder not in ("sah", "sah_device", "lbvh"):
+        raise ValueError("blas_builder must be 'sah', 'sah_device', 'lbvh' or a callable (verts, indices) -> (nodes, reordered indices)")
+    if blas_builder in ("lbvh", "sah_device") and ctx is None:
         raise LupinError(_abi_code("LUPIN_ERR_NO_DEVICE"), "the device BLAS builder needs a GPU context")
     out = Scene()
     keep = out._keep
@@ -576,6 +590,8 @@ def build_accel_structures_and_upload(ctx, scene: SceneCPU, textures: List[Textu
             nodes, reordered = np.ascontiguousarray(nodes, BVH_NODE_DTYPE), np.ascontiguousarray(reordered, np.uint32)
         elif blas_builder == "lbvh" and len(indices) >= 3 * 64:
             nodes, reordered = build_bvh_device(ctx, v, indices)
+        elif blas_builder == "sah_device" and len(indices) >= 3 * 64:
+            nodes, reordered = build_bvh_sah_device(ctx, v, indices)
         else:
             nodes, reordered = build_bvh(v, indices)
         keep += [v, nodes, reordered]
