@@ -220,10 +220,14 @@ class Scene   // lp::Scene, software-BVH configuration (renderer.rs:17-60)
     LupinScene *scene_ = nullptr;
 };
 
+// Which builder produces the BLASes: the reference's CPU builder restated (lupin_build_bvh) or the same tree built on the GPU.
+enum class BlasBuilder { Cpu, Device };
+
 // lp::build_accel_structures_and_upload (data_structures.rs:696-872): BLAS over a clone of each index buffer,
 // TLAS over the instances, lights + alias tables from the ORIGINAL triangle order, then upload.
 inline Scene build_accel_structures_and_upload(const Device &d, const SceneCPU &s, const std::vector<TextureCPU> &textures,
-                                               const std::vector<EnvMapInfo> &envs_info, bool /*build_sw_and_hw*/ = true)
+                                               const std::vector<EnvMapInfo> &envs_info, bool /*build_sw_and_hw*/ = true,
+                                               BlasBuilder blas_builder = BlasBuilder::Cpu)
 {
     if (s.environments.size() != envs_info.size()) throw Error(LUPIN_ERR_INVALID_ARGUMENT, "Mismatching sizes for environment data!");
     const size_t nm = s.verts_pos_array.size();
@@ -238,10 +242,15 @@ inline Scene build_accel_structures_and_upload(const Device &d, const SceneCPU &
         const float *vp = v.empty() ? nullptr : &v[0].x;
         static const float dummy[4] = {0, 0, 0, 0};
         if (!vp) vp = dummy;
-        int64_t n = lupin_build_bvh(vp, (uint32_t)v.size(), reordered[m].data(), (uint32_t)reordered[m].size(), nullptr, 0);
+        // 2 * triangles - 1 nodes always suffice; BlasBuilder::Device builds the same tree on the GPU (csrc/sahbvh.hip)
+        const size_t num_tris = reordered[m].size() / 3;
+        bvhs[m].resize(num_tris ? 2 * num_tris - 1 : 1);
+        const bool on_device = blas_builder == BlasBuilder::Device && num_tris >= 64;
+        const int64_t n = on_device
+            ? lupin_hip_build_bvh_sah_device(d.raw(), vp, (uint32_t)v.size(), reordered[m].data(), (uint32_t)reordered[m].size(), bvhs[m].data(), (uint64_t)bvhs[m].size())
+            : lupin_build_bvh(vp, (uint32_t)v.size(), reordered[m].data(), (uint32_t)reordered[m].size(), bvhs[m].data(), (uint64_t)bvhs[m].size());
         if (n < 0) throw Error((int)n, "build_bvh failed");
         bvhs[m].resize((size_t)n);
-        lupin_build_bvh(vp, (uint32_t)v.size(), reordered[m].data(), (uint32_t)reordered[m].size(), bvhs[m].data(), (uint64_t)n);
         float lo[3] = {3.402823466e38f, 3.402823466e38f, 3.402823466e38f}, hi[3] = {-3.402823466e38f, -3.402823466e38f, -3.402823466e38f};
         for (const Vec4 &p : v) { lo[0] = std::fmin(lo[0], p.x); lo[1] = std::fmin(lo[1], p.y); lo[2] = std::fmin(lo[2], p.z); hi[0] = std::fmax(hi[0], p.x); hi[1] = std::fmax(hi[1], p.y); hi[2] = std::fmax(hi[2], p.z); }
         for (int k = 0; k < 3; k++) { aabbs[m * 6 + k] = lo[k]; aabbs[m * 6 + 3 + k] = hi[k]; }

@@ -110,6 +110,9 @@ extern "C" {
                                             desc: *const LupinTonemapDesc) -> c_int;
     // host-side builders with the results of lupin/src/data_structures.rs
     pub fn lupin_build_bvh(verts_pos4: *const f32, num_verts: u32, indices: *mut u32, num_indices: u32, out_nodes: *mut LupinBvhNode, cap: u64) -> i64;
+    // the same tree built on the GPU (csrc/sahbvh.hip); cap = 2 * triangles - 1 always suffices
+    pub fn lupin_hip_build_bvh_sah_device(ctx: *mut LupinContext, verts_pos4: *const f32, num_verts: u32, indices: *mut u32, num_indices: u32,
+                                          out_nodes: *mut LupinBvhNode, cap: u64) -> i64;
     pub fn lupin_build_tlas(instances: *const LupinInstance, n: u32, model_aabbs: *const f32, num_meshes: u32, out: *mut LupinTlasNode) -> i64;
     pub fn lupin_build_alias_table(weights: *const f32, n: u64, out_bins: *mut LupinAliasBin) -> i64;
 }
