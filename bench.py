@@ -275,6 +275,7 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--spp", type=int, default=8, help="samples per pixel per step (baked)")
     ap.add_argument("--bounces", type=int, default=16)
+    ap.add_argument("--integrator", default="Standard", choices=["Standard", "MIS", "Naive", "Direct"], help="pathtrace type (the headline is Standard)")
     ap.add_argument("--tile-size", type=int, default=8, help="tile edge in 4-px workgroups for multi-GPU sharding")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (cpu_baseline, parity, accuracy)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel passes (roofline = null)")
@@ -307,7 +308,7 @@ def main():
     cam_params = camera_for(api, cam, W, H, keep_aspect)
     res = api.build_pathtrace_resources(ctx, api.BakedPathtraceParams(max_bounces=args.bounces, samples_per_pixel=args.spp))
     out = api.DoubleBufferedTexture(ctx, W, H)
-    ptype = api.PathtraceType.Standard
+    ptype = api.PathtraceType[args.integrator]
     frame = [0]
 
     def step():
@@ -369,7 +370,7 @@ def main():
             "metric": "Msamples/sec (paths x bounces)", "value": value, "unit": "Msamples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.scene} {W}x{H}, {args.bounces} bounces, {args.spp} spp per step, Standard integrator, software BVH "
+            "config": {"workload": f"{args.scene} {W}x{H}, {args.bounces} bounces, {args.spp} spp per step, {args.integrator} integrator, software BVH "
                                    f"(BASELINE configs[4] frame; stand-in scene for bistroexterior, SURVEY 8d)",
                        "scene": getattr(scene, "stats", None), "samples_per_pixel_per_step": args.spp,
                        "spp_total_timed": args.spp * args.steps, "frames_in_flight": int(os.environ.get("LUPIN_LANES", "3")),
@@ -396,7 +397,7 @@ def single_gpu_extras(args, api, ctx, scene, cam, cam_params, W, H, ptype):
     peak_measured = None
     if not args.no_kernel_timing:
         peak_measured = ctx.measure_copy_bandwidth(1 << 31, 6)
-        key = f"{args.scene}_{W}x{H}_b{args.bounces}_spp{args.spp}_standard"
+        key = f"{args.scene}_{W}x{H}_b{args.bounces}_spp{args.spp}_{args.integrator.lower()}"
         rec, _, _ = measure_single_gpu(api, ctx, scene, cam, W, H, args.bounces, args.spp, 2, 0, ptype, key, peak_measured,
                                        keep_aspect=(cam_params is cam.params))
         extras["roofline"] = rec.get("roofline")

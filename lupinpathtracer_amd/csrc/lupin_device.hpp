@@ -1456,7 +1456,11 @@ LP_FN float lights_pdf(const Geo &geo, const SceneDev &sc, uint32_t *stack, f3 p
     // candidates in increasing light order, so the sum below has the reference's order and the skipped terms are +0.0f.
     float mesh_pdf = 0.0f;
     const float dd = dot3(incoming, incoming);
+#ifdef LP_EXPERIMENT_NO_CULL       // timing experiments only (wrong images): neither culling nor marching
+    for (uint32_t base = sc.num_lights; base < sc.num_lights; base += 32u)
+#else
     for (uint32_t base = 0; base < sc.num_lights; base += 32u)
+#endif
     {
         const uint32_t cnt = (sc.num_lights - base) < 32u ? (sc.num_lights - base) : 32u;
         uint32_t mask = 0u;
@@ -1475,6 +1479,9 @@ LP_FN float lights_pdf(const Geo &geo, const SceneDev &sc, uint32_t *stack, f3 p
             // (the debug heat maps count every light's tests, so the counting accessor keeps them all)
             if (Geo::kCounting || reach) mask |= 1u << k;
         }
+#ifdef LP_EXPERIMENT_NO_MARCH      // timing experiments only (wrong images): culling without marching
+        mesh_pdf += (float)mask * 1e-30f; mask = 0u;
+#endif
         while (mask)
         {
         const uint32_t i = base + (uint32_t)__builtin_ctz(mask);

@@ -67,6 +67,7 @@ struct LupinContext
     int last_lane = -1;
     hipEvent_t marker = nullptr;
     bool timing = false;
+    int light_stage = 0;            // LUPIN_LIGHT_STAGE=1: sample_lights_pdf in its own stage (k_light_pdf) instead of inline in k_shade
     bool debug_sync = false;        // LUPIN_DEBUG_SYNC=1: synchronise and report after every stage launch (fault localisation)
     bool counting = false;          // lupin_hip_stats_reset(ctx, 2): the tracing kernels run their work-counting instantiation
     int accum_mode = 0;             // LUPIN_ACCUM_F16_RUNNING_AVERAGE | LUPIN_ACCUM_F32
@@ -226,6 +227,14 @@ static uint32_t persistent_grid(LupinContext *ctx, const LupinScene *scene, uint
     }
 }
 
+// LUPIN_LIGHT_STAGE=1: sample_lights_pdf of the Standard integrator runs in its own stage (k_light_pdf) instead of inline
+// in k_shade.  Same results; off by default (faster kernel for kernel, slower with frames in flight).
+static bool use_light_stage(const LupinContext *ctx, const LupinScene *scene)
+{
+    if (scene->simple_matte && ctx->specialize_simple) return false;
+    return ctx->light_stage > 0;
+}
+
 template <int TYPE, bool LDSGEO>
 static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *scene, uint32_t blocks, uint32_t pblocks, size_t lds, uint32_t stack_words, uint32_t iter)
 {
@@ -263,10 +272,23 @@ static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *sc
         hipError_t de = hipStreamSynchronize(st);
         fprintf(stderr, "[lupin] iteration %u type %d: extend done: %s\n", iter, TYPE, hipGetErrorString(de)); fflush(stderr);
     }
+    bool light_stage = false;
+    if constexpr (TYPE == LUPIN_PATHTRACE_STANDARD) light_stage = use_light_stage(ctx, scene);
     if (scene->simple_matte && ctx->specialize_simple)
         hipLaunchKernelGGL((k_shade<TYPE, LDSGEO, true>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
-    else
+    else if (!light_stage)
         hipLaunchKernelGGL((k_shade<TYPE, LDSGEO, false>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
+    if constexpr (TYPE == LUPIN_PATHTRACE_STANDARD)
+    {
+        if (light_stage)
+        {
+            // sample_lights_pdf has its own stage: k_shade tags the vertices that need it, k_light_pdf finishes them and appends
+            // (this k_shade never traverses: without LDS-staged geometry it needs the block sort's 256 words only)
+            const size_t shade_lds = LDSGEO ? lds : std::min(lds, (size_t)LP_BLOCK * sizeof(uint32_t));
+            hipLaunchKernelGGL((k_shade<TYPE, LDSGEO, false, true>), dim3(blocks), dim3(LP_BLOCK), shade_lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
+            hipLaunchKernelGGL((k_light_pdf<TYPE, LDSGEO>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, stack_words);
+        }
+    }
     if constexpr (TYPE == LUPIN_PATHTRACE_MIS || TYPE == LUPIN_PATHTRACE_DIRECT)   // shadow rays + path finish (booked with "shade" in the timing)
     {
         if (persistent && ctx->persistent_shadow)
@@ -419,6 +441,7 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
     }
     const char *dbs = getenv("LUPIN_DEBUG_SYNC");
     ctx->debug_sync = dbs && strcmp(dbs, "0") != 0;
+    if (const char *lsg = getenv("LUPIN_LIGHT_STAGE")) ctx->light_stage = atoi(lsg) != 0 ? 1 : 0;
     const char *ssh = getenv("LUPIN_SIMPLE_SHADE");
     if (ssh && strcmp(ssh, "0") == 0) ctx->specialize_simple = false;
     const char *gr = getenv("LUPIN_GRAPH");
@@ -1106,7 +1129,7 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
         n64 = (uint64_t)fp.reg_w * fp.reg_h;
     }
     if (n64 == 0) return LUPIN_OK;
-    if (n64 > 0x7FFFFFFFull) return fail(LUPIN_ERR_INVALID_ARGUMENT, "dispatch too large");
+    if (n64 > (uint64_t)QUEUE_SLOT_MASK) return fail(LUPIN_ERR_INVALID_ARGUMENT, "dispatch too large");   // queue entries keep two bits for the light-pdf stage
     const uint32_t n = (uint32_t)n64;
 
     if (falsecolor_type >= 0 || debug)

@@ -65,6 +65,9 @@ struct PathBuffers
     // always reads and appends shard b % LP_SHARDS, so a shard never grows beyond its initial size.
     uint32_t *queue[2];   // [parity][shard * shard_cap + i]
     uint32_t *counts;     // counts[k * LP_SHARDS + s] = live paths of shard s entering iteration k
+    // Light-pdf stage (k_light_pdf, Standard): k_shade does not append; it tags its queue entry with what became of the
+    // path (QUEUE_STATE_*), parks numerator and BSDF pdf of a waiting vertex in sh_f0, and k_light_pdf finishes the
+    // iteration and appends the survivors in the queue's order.
     uint32_t shard_cap;   // slots per shard (multiple of LP_BLOCK)
 };
 
@@ -210,6 +213,12 @@ __global__ void __launch_bounds__(LP_BLOCK) k_begin(const FrameParams *__restric
 #endif
 #ifndef LP_SHADE_WAVES
 #define LP_SHADE_WAVES 3
+#endif
+#ifndef LP_DEFER_SHADE_WAVES
+#define LP_DEFER_SHADE_WAVES 4   // k_shade without the light-pdf march (the light-pdf stage runs it)
+#endif
+#ifndef LP_LIGHT_PDF_WAVES
+#define LP_LIGHT_PDF_WAVES 4
 #endif
 #ifndef LP_SIMPLE_SHADE_WAVES
 #define LP_SIMPLE_SHADE_WAVES 4
@@ -585,7 +594,24 @@ struct PathRegs
     bool in_medium;       // volume_stack_len == 1
     bool next_emission;
     Medium medium;
+    // deferred weight update (light-pdf stage): weight *= pend_f / (0.5 pend_bp + 0.5 sample_lights_pdf(ori, dir))
+    bool pending;
+    f3 pend_f;
+    float pend_bp;
 };
+
+// weight check and Russian roulette (:720-729)
+__device__ __forceinline__ bool weight_checks_and_roulette(PathRegs &p)
+{
+    if (is_zero3(p.weight) || !finite3(p.weight)) return false;
+    if (p.bounce > 3)
+    {
+        float survive = minf(0.99f, maxf(p.weight.x, maxf(p.weight.y, p.weight.z)));
+        if (rnd(p.rng) >= survive) return false;
+        p.weight = scale(p.weight, 1.0f / survive);
+    }
+    return true;
+}
 
 // One iteration of the integrator loop body after the closest-hit query.  Returns true when the
 // path continues with (ori, dir) set for the next bounce, false on `break`.
@@ -595,12 +621,17 @@ struct PathRegs
 // call passes SceneDev / PathRegs / ShadowRays through scratch memory, which is slow ("outlined helpers") and,
 // on ROCm 7.2, faulted: pointers of the scratch copy of SceneDev read back as material data (address = the bits of
 // {roughness, metallic}) in k_shade<Direct> on materials4.
-template <int TYPE, typename Geo, bool SIMPLE = false>
+// DEFER (Standard only): the vertex stops before `sample_lights_pdf` -- the numerator and the BSDF pdf go to p.pend_*, and
+// k_light_pdf finishes the iteration (weight, checks, Russian roulette: no random number is drawn in between, so the
+// sequence of draws is the reference's).
+template <int TYPE, typename Geo, bool SIMPLE = false, bool DEFER = false>
 __device__ __forceinline__ bool integrate_vertex(const Geo &geo, const SceneDev &sc, uint32_t *stack, const FrameParams &fp, PathRegs &p,
                                  float4 hitrec, uint32_t hit_tri, ShadowRays &sh)
 {
+    static_assert(!DEFER || TYPE == LUPIN_PATHTRACE_STANDARD, "the light-pdf stage serves the Standard integrator");
     const float eps = fp.pc.ray_epsilon;
     const uint32_t hit_inst = __float_as_uint(hitrec.w);
+    p.pending = false;
     if (hit_inst == HIT_MISS)
     {
         if (TYPE != LUPIN_PATHTRACE_DIRECT || p.next_emission)
@@ -668,8 +699,17 @@ __device__ __forceinline__ bool integrate_vertex(const Geo &geo, const SceneDev 
                 }
                 else incoming = lights_sample(sc, hit_pos, p.rng);
                 if (is_zero3(incoming)) return false;
-                float prob = 0.5f * bsdf_pdf(mp, normal, outgoing, incoming) + 0.5f * lights_pdf(geo, sc, stack, hit_pos, incoming, eps);
-                p.weight = mul(p.weight, divs(bsdf_eval(mp, normal, outgoing, incoming), prob));
+                if (DEFER)
+                {
+                    p.pend_bp = bsdf_pdf(mp, normal, outgoing, incoming);
+                    p.pend_f = bsdf_eval(mp, normal, outgoing, incoming);
+                    p.pending = true;
+                }
+                else
+                {
+                    float prob = 0.5f * bsdf_pdf(mp, normal, outgoing, incoming) + 0.5f * lights_pdf(geo, sc, stack, hit_pos, incoming, eps);
+                    p.weight = mul(p.weight, divs(bsdf_eval(mp, normal, outgoing, incoming), prob));
+                }
             }
             else if (TYPE == LUPIN_PATHTRACE_NAIVE)
             {
@@ -760,91 +800,38 @@ __device__ __forceinline__ bool integrate_vertex(const Geo &geo, const SceneDev 
             else incoming = lights_sample(sc, hit_pos, p.rng);
             if (TYPE == LUPIN_PATHTRACE_MIS) p.next_emission = true;
             if (is_zero3(incoming)) return false;
-            float prob = 0.5f * phase_pdf(p.medium, outgoing, incoming) + 0.5f * lights_pdf(geo, sc, stack, hit_pos, incoming, eps);
-            p.weight = mul(p.weight, divs(phase_eval(p.medium, outgoing, incoming), prob));
+            if (DEFER)
+            {
+                p.pend_bp = phase_pdf(p.medium, outgoing, incoming);
+                p.pend_f = phase_eval(p.medium, outgoing, incoming);
+                p.pending = true;
+            }
+            else
+            {
+                float prob = 0.5f * phase_pdf(p.medium, outgoing, incoming) + 0.5f * lights_pdf(geo, sc, stack, hit_pos, incoming, eps);
+                p.weight = mul(p.weight, divs(phase_eval(p.medium, outgoing, incoming), prob));
+            }
         }
     }
 
     p.ori = hit_pos;
     p.dir = incoming;
-
-    // weight check and Russian roulette (:720-729)
-    if (is_zero3(p.weight) || !finite3(p.weight)) return false;
-    if (p.bounce > 3)
-    {
-        float survive = minf(0.99f, maxf(p.weight.x, maxf(p.weight.y, p.weight.z)));
-        if (rnd(p.rng) >= survive) return false;
-        p.weight = scale(p.weight, 1.0f / survive);
-    }
-    return true;
+    if (DEFER && p.pending) return true;
+    return weight_checks_and_roulette(p);
 }
 
-// Everything of one integrator-loop iteration after the closest-hit query, for one path; writes the path state
-// back and returns whether the pixel still has work (the path continues, or its next camera sample was started).
-template <int TYPE, typename Geo, bool SIMPLE = false>
-__device__ __forceinline__ bool shade_path(const Geo &geo, const SceneDev &sc, uint32_t *stack, const FrameParams &fp, PathBuffers &pb,
-                                           uint32_t slot, float4 orr, float4 dm, uint32_t rng, float4 hitrec, uint32_t hit_tri)
+// End of an iteration of the Standard / Naive loop for one path: a continuing path gets its state written back, a finished
+// one is folded into the pixel and the pixel's next camera sample started (:234-239).  `r4` is the radiance as stored (only
+// emitters change it).  Returns whether the slot still has work.
+template <int TYPE>
+__device__ __forceinline__ bool path_epilogue(const FrameParams &fp, PathBuffers &pb, uint32_t slot, PathRegs &p, uint32_t sample, bool cont,
+                                              bool vol_dirty, float4 r4)
 {
     bool alive = false;
-    float4 w4 = pb.weight[slot];
-    float4 r4 = pb.radiance[slot];
-    uint32_t meta = __float_as_uint(dm.w);
-
-    PathRegs p;
-    p.ori = mk3(orr.x, orr.y, orr.z);
-    p.dir = mk3(dm.x, dm.y, dm.z);
-    p.weight = mk3(w4.x, w4.y, w4.z);
-    p.radiance = mk3(r4.x, r4.y, r4.z);
-    p.rng = rng;
-    p.bounce = (int)(meta & META_BOUNCE_MASK);
-    p.in_medium = SIMPLE ? false : (meta & META_VOLUME) != 0;   // matte surfaces never open a medium
-    p.next_emission = (meta & META_NEXT_EMISSION) != 0;
-    uint32_t sample = meta >> META_SAMPLE_SHIFT;
-    const bool was_in_medium = p.in_medium;
-    if (p.in_medium)
-    {
-        float4 a = pb.vol0[slot], b = pb.vol1[slot];
-        p.medium.density = mk3(a.x, a.y, a.z);
-        p.medium.anisotropy = a.w;
-        p.medium.scattering = mk3(b.x, b.y, b.z);
-    }
-    else { p.medium.density = splat(0.0f); p.medium.scattering = splat(0.0f); p.medium.anisotropy = 0.0f; }
-
-    ShadowRays sh;
-    sh.v0 = sh.v1 = false;
-    bool cont = integrate_vertex<TYPE, Geo, SIMPLE>(geo, sc, stack, fp, p, hitrec, hit_tri, sh);
-    if (cont)
-    {
-        p.bounce++;
-        if (p.bounce > (int)fp.max_bounces) cont = false;   // loop condition `bounce <= MAX_BOUNCES` (:596)
-    }
-
-    if (TYPE == LUPIN_PATHTRACE_MIS || TYPE == LUPIN_PATHTRACE_DIRECT)
-    {
-        // hand the vertex to k_shadow: it adds the shadow-ray terms to `radiance` (the order of the additions is the
-        // reference's) and only then folds a finished path into the pixel / starts the next sample
-        if (p.in_medium && !was_in_medium)
-        {
-            pb.vol0[slot] = make_float4(p.medium.density.x, p.medium.density.y, p.medium.density.z, p.medium.anisotropy);
-            pb.vol1[slot] = make_float4(p.medium.scattering.x, p.medium.scattering.y, p.medium.scattering.z, 0.0f);
-        }
-        pb.weight[slot] = make_float4(p.weight.x, p.weight.y, p.weight.z, 0.0f);
-        pb.radiance[slot] = make_float4(p.radiance.x, p.radiance.y, p.radiance.z, 0.0f);
-        const uint32_t nm = ((uint32_t)p.bounce & META_BOUNCE_MASK) | (p.in_medium ? META_VOLUME : 0u) |
-                            (p.next_emission ? META_NEXT_EMISSION : 0u) | (cont ? 0u : META_TERMINATED) | (sample << META_SAMPLE_SHIFT);
-        pb.ori_rng[slot] = make_float4(p.ori.x, p.ori.y, p.ori.z, __uint_as_float(p.rng));
-        pb.dir_meta[slot] = make_float4(p.dir.x, p.dir.y, p.dir.z, __uint_as_float(nm));
-        const uint32_t flags = (sh.v0 ? 1u : 0u) | (sh.v1 ? 2u : 0u);
-        pb.sh_org[slot] = make_float4(sh.org.x, sh.org.y, sh.org.z, __uint_as_float(flags));
-        if (sh.v0) { pb.sh_d0[slot] = make_float4(sh.d0.x, sh.d0.y, sh.d0.z, sh.s0); pb.sh_f0[slot] = make_float4(sh.f0.x, sh.f0.y, sh.f0.z, 0.0f); }
-        if (sh.v1) { pb.sh_d1[slot] = make_float4(sh.d1.x, sh.d1.y, sh.d1.z, sh.s1); pb.sh_f1[slot] = make_float4(sh.f1.x, sh.f1.y, sh.f1.z, 0.0f); }
-        return true;
-    }
-
     if (cont)
     {
         alive = true;
-        if (p.in_medium && !was_in_medium)
+        if (vol_dirty)
         {
             pb.vol0[slot] = make_float4(p.medium.density.x, p.medium.density.y, p.medium.density.z, p.medium.anisotropy);
             pb.vol1[slot] = make_float4(p.medium.scattering.x, p.medium.scattering.y, p.medium.scattering.z, 0.0f);
@@ -855,7 +842,6 @@ __device__ __forceinline__ bool shade_path(const Geo &geo, const SceneDev &sc, u
     }
     else
     {
-        // path finished: fold its radiance into the pixel, start the pixel's next sample (:234-239)
         float4 c4 = pb.color[slot];
         f3 cr = clamp_radiance(p.radiance, fp.pc.max_radiance);
         pb.color[slot] = make_float4(c4.x + cr.x, c4.y + cr.y, c4.z + cr.z, 0.0f);
@@ -888,11 +874,131 @@ __device__ __forceinline__ bool shade_path(const Geo &geo, const SceneDev &sc, u
     return alive;
 }
 
+enum : int { SLOT_DONE = 0, SLOT_ALIVE = 1, SLOT_WAITS_FOR_LIGHT_PDF = 2 };
+// k_shade -> k_light_pdf: the queue entry carries the slot and, above it, what became of the path in k_shade
+constexpr uint32_t QUEUE_STATE_SHIFT = 30u, QUEUE_SLOT_MASK = (1u << QUEUE_STATE_SHIFT) - 1u, QUEUE_ENTRY_NONE = 0xFFFFFFFFu;
+
+// Everything of one integrator-loop iteration after the closest-hit query, for one path; writes the path state
+// back and returns whether the pixel still has work (the path continues, or its next camera sample was started) or, with
+// DEFER, waits for the light-pdf stage.
+template <int TYPE, typename Geo, bool SIMPLE = false, bool DEFER = false>
+__device__ __forceinline__ int shade_path(const Geo &geo, const SceneDev &sc, uint32_t *stack, const FrameParams &fp, PathBuffers &pb,
+                                          uint32_t slot, float4 orr, float4 dm, uint32_t rng, float4 hitrec, uint32_t hit_tri)
+{
+    float4 w4 = pb.weight[slot];
+    float4 r4 = pb.radiance[slot];
+    uint32_t meta = __float_as_uint(dm.w);
+
+    PathRegs p;
+    p.ori = mk3(orr.x, orr.y, orr.z);
+    p.dir = mk3(dm.x, dm.y, dm.z);
+    p.weight = mk3(w4.x, w4.y, w4.z);
+    p.radiance = mk3(r4.x, r4.y, r4.z);
+    p.rng = rng;
+    p.bounce = (int)(meta & META_BOUNCE_MASK);
+    p.in_medium = SIMPLE ? false : (meta & META_VOLUME) != 0;   // matte surfaces never open a medium
+    p.next_emission = (meta & META_NEXT_EMISSION) != 0;
+    uint32_t sample = meta >> META_SAMPLE_SHIFT;
+    const bool was_in_medium = p.in_medium;
+    if (p.in_medium)
+    {
+        float4 a = pb.vol0[slot], b = pb.vol1[slot];
+        p.medium.density = mk3(a.x, a.y, a.z);
+        p.medium.anisotropy = a.w;
+        p.medium.scattering = mk3(b.x, b.y, b.z);
+    }
+    else { p.medium.density = splat(0.0f); p.medium.scattering = splat(0.0f); p.medium.anisotropy = 0.0f; }
+
+    ShadowRays sh;
+    sh.v0 = sh.v1 = false;
+    bool cont = integrate_vertex<TYPE, Geo, SIMPLE, DEFER>(geo, sc, stack, fp, p, hitrec, hit_tri, sh);
+    const bool vol_dirty = p.in_medium && !was_in_medium;
+    if (DEFER && cont && p.pending)
+    {
+        // k_light_pdf finishes this iteration: park what it needs (the bounce count is still this iteration's)
+        if (vol_dirty)
+        {
+            pb.vol0[slot] = make_float4(p.medium.density.x, p.medium.density.y, p.medium.density.z, p.medium.anisotropy);
+            pb.vol1[slot] = make_float4(p.medium.scattering.x, p.medium.scattering.y, p.medium.scattering.z, 0.0f);
+        }
+        if (was_in_medium) pb.weight[slot] = make_float4(p.weight.x, p.weight.y, p.weight.z, 0.0f);   // only the transmittance term changed it
+        if (p.radiance.x != r4.x || p.radiance.y != r4.y || p.radiance.z != r4.z)
+            pb.radiance[slot] = make_float4(p.radiance.x, p.radiance.y, p.radiance.z, 0.0f);
+        pb.sh_f0[slot] = make_float4(p.pend_f.x, p.pend_f.y, p.pend_f.z, p.pend_bp);
+        const uint32_t nm = ((uint32_t)p.bounce & META_BOUNCE_MASK) | (p.in_medium ? META_VOLUME : 0u) |
+                            (p.next_emission ? META_NEXT_EMISSION : 0u) | (sample << META_SAMPLE_SHIFT);
+        pb.ori_rng[slot] = make_float4(p.ori.x, p.ori.y, p.ori.z, __uint_as_float(p.rng));
+        pb.dir_meta[slot] = make_float4(p.dir.x, p.dir.y, p.dir.z, __uint_as_float(nm));
+        return SLOT_WAITS_FOR_LIGHT_PDF;
+    }
+    if (cont)
+    {
+        p.bounce++;
+        if (p.bounce > (int)fp.max_bounces) cont = false;   // loop condition `bounce <= MAX_BOUNCES` (:596)
+    }
+
+    if (TYPE == LUPIN_PATHTRACE_MIS || TYPE == LUPIN_PATHTRACE_DIRECT)
+    {
+        // hand the vertex to k_shadow: it adds the shadow-ray terms to `radiance` (the order of the additions is the
+        // reference's) and only then folds a finished path into the pixel / starts the next sample
+        if (vol_dirty)
+        {
+            pb.vol0[slot] = make_float4(p.medium.density.x, p.medium.density.y, p.medium.density.z, p.medium.anisotropy);
+            pb.vol1[slot] = make_float4(p.medium.scattering.x, p.medium.scattering.y, p.medium.scattering.z, 0.0f);
+        }
+        pb.weight[slot] = make_float4(p.weight.x, p.weight.y, p.weight.z, 0.0f);
+        pb.radiance[slot] = make_float4(p.radiance.x, p.radiance.y, p.radiance.z, 0.0f);
+        const uint32_t nm = ((uint32_t)p.bounce & META_BOUNCE_MASK) | (p.in_medium ? META_VOLUME : 0u) |
+                            (p.next_emission ? META_NEXT_EMISSION : 0u) | (cont ? 0u : META_TERMINATED) | (sample << META_SAMPLE_SHIFT);
+        pb.ori_rng[slot] = make_float4(p.ori.x, p.ori.y, p.ori.z, __uint_as_float(p.rng));
+        pb.dir_meta[slot] = make_float4(p.dir.x, p.dir.y, p.dir.z, __uint_as_float(nm));
+        const uint32_t flags = (sh.v0 ? 1u : 0u) | (sh.v1 ? 2u : 0u);
+        pb.sh_org[slot] = make_float4(sh.org.x, sh.org.y, sh.org.z, __uint_as_float(flags));
+        if (sh.v0) { pb.sh_d0[slot] = make_float4(sh.d0.x, sh.d0.y, sh.d0.z, sh.s0); pb.sh_f0[slot] = make_float4(sh.f0.x, sh.f0.y, sh.f0.z, 0.0f); }
+        if (sh.v1) { pb.sh_d1[slot] = make_float4(sh.d1.x, sh.d1.y, sh.d1.z, sh.s1); pb.sh_f1[slot] = make_float4(sh.f1.x, sh.f1.y, sh.f1.z, 0.0f); }
+        return SLOT_ALIVE;
+    }
+    return path_epilogue<TYPE>(fp, pb, slot, p, sample, cont, vol_dirty, r4) ? SLOT_ALIVE : SLOT_DONE;
+}
+
+// The light-pdf stage's share of an iteration (Standard): sample_lights_pdf for the direction k_shade chose
+// (pathtracer.wgsl:2516-2549 -> bvh_custom.wgsl:112-152), the weight update it feeds (:652-656), the weight checks,
+// Russian roulette and the loop condition (:720-729, :596).
+template <int TYPE, typename Geo>
+__device__ __forceinline__ bool light_pdf_path(const Geo &geo, const SceneDev &sc, uint32_t *stack, const FrameParams &fp, PathBuffers &pb, uint32_t slot)
+{
+    const float4 orr = pb.ori_rng[slot], dm = pb.dir_meta[slot], w4 = pb.weight[slot], pd = pb.sh_f0[slot];
+    const uint32_t meta = __float_as_uint(dm.w);
+    PathRegs p;
+    p.ori = mk3(orr.x, orr.y, orr.z);
+    p.dir = mk3(dm.x, dm.y, dm.z);
+    p.weight = mk3(w4.x, w4.y, w4.z);
+    p.rng = __float_as_uint(orr.w);
+    p.bounce = (int)(meta & META_BOUNCE_MASK);
+    p.in_medium = (meta & META_VOLUME) != 0;
+    p.next_emission = (meta & META_NEXT_EMISSION) != 0;
+    p.pending = false;
+    const uint32_t sample = meta >> META_SAMPLE_SHIFT;
+
+    const float prob = 0.5f * pd.w + 0.5f * lights_pdf(geo, sc, stack, p.ori, p.dir, fp.pc.ray_epsilon);
+    p.weight = mul(p.weight, divs(mk3(pd.x, pd.y, pd.z), prob));
+    bool cont = weight_checks_and_roulette(p);
+    if (cont)
+    {
+        p.bounce++;
+        if (p.bounce > (int)fp.max_bounces) cont = false;
+    }
+    float4 r4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (!cont) r4 = pb.radiance[slot];   // a finished path is folded into the pixel
+    p.radiance = mk3(r4.x, r4.y, r4.z);
+    return path_epilogue<TYPE>(fp, pb, slot, p, sample, cont, false, r4);
+}
+
 // SIMPLE: scenes of untextured matte surfaces without environments (LupinScene::simple_matte, decided at upload) get a
 // k_shade in which those facts are compile-time constants: same arithmetic on the paths that exist, none of the code
 // for the ones that cannot.
-template <int TYPE, bool LDSGEO, bool SIMPLE>
-__global__ void __attribute__((amdgpu_waves_per_eu(TYPE == 1 ? LP_MIS_SHADE_WAVES : (SIMPLE ? LP_SIMPLE_SHADE_WAVES : LP_SHADE_WAVES), 8))) __launch_bounds__(LP_BLOCK) k_shade(SceneDev sc, const FrameParams *__restrict__ fpp, PathBuffers pb, uint32_t iter,
+template <int TYPE, bool LDSGEO, bool SIMPLE, bool DEFER = false>
+__global__ void __attribute__((amdgpu_waves_per_eu(TYPE == 1 ? LP_MIS_SHADE_WAVES : (SIMPLE ? LP_SIMPLE_SHADE_WAVES : (DEFER ? LP_DEFER_SHADE_WAVES : LP_SHADE_WAVES)), 8))) __launch_bounds__(LP_BLOCK) k_shade(SceneDev sc, const FrameParams *__restrict__ fpp, PathBuffers pb, uint32_t iter,
                                                     unsigned long long *shard_stats, uint32_t stack_words)
 {
     const FrameParams fp = *fpp;
@@ -902,7 +1008,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(TYPE == 1 ? LP_MIS_SHADE_WAVE
     const uint32_t shard = blockIdx.x % LP_SHARDS;
     const uint32_t count = pb.counts[iter * LP_SHARDS + shard];
     const uint32_t i = (blockIdx.x / LP_SHARDS) * LP_BLOCK + threadIdx.x;
-    bool alive = false;
+    int state = SLOT_DONE;
     bool mine = i < count;
     uint32_t slot = 0;
     if (mine) slot = pb.queue[iter & 1][(size_t)shard * pb.shard_cap + i];
@@ -934,10 +1040,59 @@ __global__ void __attribute__((amdgpu_waves_per_eu(TYPE == 1 ? LP_MIS_SHADE_WAVE
     if (mine)
     {
         const float4 orr = pb.ori_rng[slot];
-        alive = shade_path<TYPE, typename GeoOf<LDSGEO>::type, SIMPLE>(geo, sc, lds_stack, fp, pb, slot, orr, pb.dir_meta[slot], __float_as_uint(orr.w), pb.hit[slot], pb.hit_tri[slot]);
+        state = shade_path<TYPE, typename GeoOf<LDSGEO>::type, SIMPLE, DEFER>(geo, sc, lds_stack, fp, pb, slot, orr, pb.dir_meta[slot], __float_as_uint(orr.w), pb.hit[slot], pb.hit_tri[slot]);
     }
     if (i == 0 && iter == 0) shard_stats[shard * 2 + 1] += (unsigned long long)count * fp.spp;
     if (TYPE == LUPIN_PATHTRACE_MIS || TYPE == LUPIN_PATHTRACE_DIRECT) return;   // k_shadow appends
+    if (DEFER)
+    {
+        // with the block sort, thread i shaded some other entry of its block: the tagged entries are a permutation of the block's
+        if (i < count) pb.queue[iter & 1][(size_t)shard * pb.shard_cap + i] = mine ? (slot | ((uint32_t)state << QUEUE_STATE_SHIFT)) : QUEUE_ENTRY_NONE;
+        return;
+    }
+    queue_append(state == SLOT_ALIVE, slot, pb.queue[(iter + 1) & 1] + (size_t)shard * pb.shard_cap, &pb.counts[(iter + 1) * LP_SHARDS + shard]);
+}
+
+// Light-pdf stage: walks the iteration's queue again.  The block's waiting vertices are compacted to its first threads (so
+// all lanes of a wave march, except in the block's last active wave), finished there, and the verdicts go back to the
+// entries' own threads: the append keeps the queue's order, which the persistent tracer's static partition relies on for
+// balance (survivors appended behind k_shade's own appends cost k_extend 4 %).
+template <int TYPE, bool LDSGEO>
+__global__ void __attribute__((amdgpu_waves_per_eu(LP_LIGHT_PDF_WAVES, 8))) __launch_bounds__(LP_BLOCK) k_light_pdf(SceneDev sc, const FrameParams *__restrict__ fpp, PathBuffers pb, uint32_t iter, uint32_t stack_words)
+{
+    const FrameParams fp = *fpp;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+    __shared__ uint32_t waiting[LP_BLOCK];        // compacted: thread index of the waiting entry
+    __shared__ uint32_t entry_slot[LP_BLOCK];
+    __shared__ uint32_t verdict[LP_BLOCK];
+    __shared__ uint32_t wave_total[LP_BLOCK / 64];
+    const auto geo = make_geo<LDSGEO>(sc, lds_stack, stack_words);
+    const uint32_t shard = blockIdx.x % LP_SHARDS;
+    const uint32_t count = pb.counts[iter * LP_SHARDS + shard];
+    const uint32_t i = (blockIdx.x / LP_SHARDS) * LP_BLOCK + threadIdx.x;
+    if ((blockIdx.x / LP_SHARDS) * LP_BLOCK >= count) return;   // block-uniform
+    uint32_t *entries = pb.queue[iter & 1] + (size_t)shard * pb.shard_cap + (size_t)(blockIdx.x / LP_SHARDS) * LP_BLOCK;
+    const uint32_t entry = i < count ? entries[threadIdx.x] : QUEUE_ENTRY_NONE;
+    const uint32_t state = entry == QUEUE_ENTRY_NONE ? (uint32_t)SLOT_DONE : entry >> QUEUE_STATE_SHIFT;
+    const uint32_t slot = entry & QUEUE_SLOT_MASK;
+    const bool waits = state == (uint32_t)SLOT_WAITS_FOR_LIGHT_PDF;
+    const unsigned long long wmask = __ballot(waits);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) wave_total[wave] = (uint32_t)__popcll(wmask);
+    verdict[threadIdx.x] = 0u;
+    entry_slot[threadIdx.x] = slot;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (uint32_t w = 0; w < LP_BLOCK / 64; w++) { const uint32_t c = wave_total[w]; if (w < wave) before += c; total += c; }
+    if (waits) waiting[before + (uint32_t)__popcll(wmask & ((1ull << lane) - 1ull))] = threadIdx.x;
+    __syncthreads();
+    if (threadIdx.x < total)
+    {
+        const uint32_t w = waiting[threadIdx.x];
+        if (light_pdf_path<TYPE, typename GeoOf<LDSGEO>::type>(geo, sc, lds_stack, fp, pb, entry_slot[w])) verdict[w] = 1u;
+    }
+    __syncthreads();
+    const bool alive = state == (uint32_t)SLOT_ALIVE || (waits && verdict[threadIdx.x] != 0u);
     queue_append(alive, slot, pb.queue[(iter + 1) & 1] + (size_t)shard * pb.shard_cap, &pb.counts[(iter + 1) * LP_SHARDS + shard]);
 }
 
