@@ -65,6 +65,7 @@ struct PathBuffers
     // always reads and appends shard b % LP_SHARDS, so a shard never grows beyond its initial size.
     uint32_t *queue[2];   // [parity][shard * shard_cap + i]
     uint32_t *counts;     // counts[k * LP_SHARDS + s] = live paths of shard s entering iteration k
+    uint32_t *cursors;    // cursors[(2 k + mode) * LP_SHARDS + s]: how much of shard s the persistent tracer's waves have taken in iteration k
     // Light-pdf stage (k_light_pdf, Standard): k_shade does not append; it tags its queue entry with what became of the
     // path (QUEUE_STATE_*), parks numerator and BSDF pdf of a waiting vertex in sh_f0, and k_light_pdf finishes the
     // iteration and appends the survivors in the queue's order.
@@ -334,9 +335,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launc
 // one-ray-per-lane kernel keeps 11 % of the VALU lanes busy on the bistro-class scene (39 % on the Cornell box; PMC:
 // SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU * 64)).  Here each wave owns its lanes for the whole launch, refills empty
 // lanes whenever at least `refill_min` of them are free, and executes per round the one phase most lanes wait for.
-// Work is partitioned statically, so refilling needs no atomics: the grid holds `wps` waves per shard, and wave j of
-// shard s owns the 64-entry chunks j, j + wps, j + 2 wps, ... of that shard's queue.  Every ray is still traced by
-// exactly the same sequence of operations as in k_extend, only by a different lane.
+// The waves of the grid are dealt to the shards round-robin and the waves of a shard hand its queue out among themselves
+// (one atomic per refill).  Every ray is still traced by exactly the same sequence of operations as in k_extend, only by
+// a different lane.
 #ifndef LP_REFILL_MIN
 #define LP_REFILL_MIN 16
 #endif
@@ -361,17 +362,16 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
     const uint32_t *queue = pb.queue[iter & 1];
     if (MODE == 0 && blockIdx.x == 0 && tid < LP_SHARDS) { const uint32_t c = counts[tid]; if (c) shard_stats[tid * 2 + 0] += c; }   // one writer per shard per launch
 
-    // this wave's share of the work
+    // The grid holds `wps` waves per shard; the waves of a shard hand its queue out among themselves, one atomic per
+    // refill (a static share per wave leaves the launch waiting for the wave whose few hundred rays happened to be the
+    // deep ones: with 1 M rays per launch -- an eighth of the 4K frame -- the tracer ran at half its large-launch rate).
     const uint32_t wave = blockIdx.x * (LP_BLOCK / 64) + tid / 64;         // wave-uniform
-    const uint32_t wps = (gridDim.x * (LP_BLOCK / 64)) / LP_SHARDS;         // waves per shard (grid is a multiple of 64 blocks)
-    const uint32_t shard = wave % LP_SHARDS, j = wave / LP_SHARDS;
+    const uint32_t shard = wave % LP_SHARDS;
     const uint32_t cnt = counts[shard] * (MODE == 1 ? 2u : 1u);   // jobs
-    const uint32_t full_chunks = cnt / 64u;
-    uint32_t n_mine = (full_chunks > j) ? ((full_chunks - j - 1u) / wps + 1u) * 64u : 0u;
-    if ((cnt % 64u) && (full_chunks % wps) == j) n_mine += cnt % 64u;       // the partial last chunk
-    if (n_mine == 0) return;
+    if (cnt == 0) return;
+    uint32_t *cursor = pb.cursors + ((size_t)iter * 2u + (MODE == 1 ? 1u : 0u)) * LP_SHARDS + shard;
     const size_t shard_base = (size_t)shard * pb.shard_cap;
-    uint32_t next_pos = 0;                                                  // position in this wave's private sequence
+    bool exhausted = false;                                                 // wave-uniform: the shard's queue is handed out
 
     const float eps = fp.pc.ray_epsilon;
     constexpr uint32_t REF_DONE = 0xFFFFFFFFu;
@@ -415,15 +415,17 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
         const uint32_t cN = (uint32_t)__popcll(__ballot(isN)), cI = (uint32_t)__popcll(__ballot(isI));
         const uint32_t cT = (uint32_t)__popcll(__ballot(isT)), cF = (uint32_t)__popcll(__ballot(isF));
 
-        if (cE >= refill_min && next_pos < n_mine)
+        if (cE >= refill_min && !exhausted)
         {
             // ---- refill empty lanes ----
             const uint32_t my_rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-            const uint32_t take = min(cE, n_mine - next_pos);
+            uint32_t first = 0;
+            if (lane == 0) first = atomicAdd(cursor, cE);
+            first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+            const uint32_t take = first < cnt ? min(cE, cnt - first) : 0u;
+            exhausted = take < cE;
             const bool got = !active && my_rank < take;
-            const uint32_t pos = next_pos + my_rank;
-            const size_t q_index = shard_base + (size_t)((pos / 64u) * wps + j) * 64u + pos % 64u;
-            next_pos += take;
+            const size_t q_index = shard_base + first + my_rank;
             if (got && MODE == 0)
             {
                 slot = queue[q_index];
