@@ -4,7 +4,8 @@
    would leave them, lupin_hip_unpack_gathered_tiles scatters them -- every rank's frame must equal the single dispatch.
 2. lupin_hip_gather_framebuffer through a real RCCL communicator of world size 1 (rendezvous file, ncclCommInitRank,
    ncclAllGather on the context's stream), with HIP-graph replay on when LUPIN_GRAPH=1 is set by the caller.
-3. exactly one HIP runtime is mapped in the process, the one the library was built against."""
+3. exactly one HIP runtime is mapped in the process, the one the library was built against.
+4. lupin_hip_comm_init_all / lupin_hip_gather_framebuffer_all (one process, one context per device) with the one device at hand."""
 import os
 import sys
 
@@ -59,3 +60,20 @@ assert float(comm.allreduce([3.0, 4.0], "sum")[1]) == 4.0 and float(comm.allredu
 comm.barrier()
 comm.close()
 print("GATHER OK")
+
+# 4. the one-process-N-contexts layout (lupin_hip_comm_init_all + lupin_hip_gather_framebuffer_all, one RCCL group) with the
+#    one device this box has: same frames, same result
+(comm1,) = api.Comm.init_all([ctx])
+assert (comm1.rank, comm1.world) == (0, 1)
+out = api.DoubleBufferedTexture(ctx, W, H)
+for k in range(3):
+    api.pathtrace_scene_tiles(ctx, res, scene, out.front(), 0,
+                              api.PathtraceDesc(accum_params=api.AccumulationParams(out.back(), k), camera_params=cam.params, camera_transform=cam.transform),
+                              ts, 0, 1)
+    api.gather_framebuffer_all([comm1], [out.front()], ts)
+    out.flip()
+out.flip()
+ref = util.gpu_accumulate(ctx, scene, cam, W, H, frames=3, spp=2, max_bounces=5)
+assert util.f16_words_differ(out.front().download(), ref) == 0
+comm1.close()
+print("INIT_ALL OK")

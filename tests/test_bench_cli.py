@@ -56,7 +56,7 @@ def test_distributed_bench_path_on_one_gpu(built, graph):
 def test_gather_through_the_c_abi(built, graph):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_gather_worker.py")], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, LUPIN_GRAPH=graph))
-    assert p.returncode == 0 and "SCATTER OK" in p.stdout and "GATHER OK" in p.stdout, p.stdout[-1500:] + p.stderr[-1500:]
+    assert p.returncode == 0 and all(tag in p.stdout for tag in ("SCATTER OK", "GATHER OK", "INIT_ALL OK")), p.stdout[-1500:] + p.stderr[-1500:]
 
 
 def test_gpus_n_without_launcher_spawns_ranks_or_fails(built):
