@@ -230,7 +230,7 @@ static uint32_t persistent_grid(LupinContext *ctx, const LupinScene *scene, uint
     }
 }
 
-// LUPIN_LIGHT_STAGE=1: sample_lights_pdf of the Standard integrator runs in its own stage (k_light_pdf) instead of inline
+// LUPIN_LIGHT_STAGE=1: sample_lights_pdf of the Standard / MIS integrators runs in its own stage (k_light_pdf / k_light_pdf_mis) instead of inline
 // in k_shade.  Same results; off by default (faster kernel for kernel, slower with frames in flight).
 static bool use_light_stage(const LupinContext *ctx, const LupinScene *scene)
 {
@@ -276,7 +276,7 @@ static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *sc
         fprintf(stderr, "[lupin] iteration %u type %d: extend done: %s\n", iter, TYPE, hipGetErrorString(de)); fflush(stderr);
     }
     bool light_stage = false;
-    if constexpr (TYPE == LUPIN_PATHTRACE_STANDARD) light_stage = use_light_stage(ctx, scene);
+    if constexpr (TYPE == LUPIN_PATHTRACE_STANDARD || TYPE == LUPIN_PATHTRACE_MIS) light_stage = use_light_stage(ctx, scene);
     if (scene->simple_matte && ctx->specialize_simple)
         hipLaunchKernelGGL((k_shade<TYPE, LDSGEO, true>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
     else if (!light_stage)
@@ -290,6 +290,15 @@ static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *sc
             const size_t shade_lds = LDSGEO ? lds : std::min(lds, (size_t)LP_BLOCK * sizeof(uint32_t));
             hipLaunchKernelGGL((k_shade<TYPE, LDSGEO, false, true>), dim3(blocks), dim3(LP_BLOCK), shade_lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
             hipLaunchKernelGGL((k_light_pdf<TYPE, LDSGEO>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, stack_words);
+        }
+    }
+    if constexpr (TYPE == LUPIN_PATHTRACE_MIS)
+    {
+        if (light_stage)
+        {
+            // the two MIS weights per vertex need sample_lights_pdf: k_shade parks the candidates, this pass weighs them
+            hipLaunchKernelGGL((k_shade<TYPE, LDSGEO, false, true>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
+            hipLaunchKernelGGL((k_light_pdf_mis<LDSGEO>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, stack_words);
         }
     }
     if constexpr (TYPE == LUPIN_PATHTRACE_MIS || TYPE == LUPIN_PATHTRACE_DIRECT)   // shadow rays + path finish (booked with "shade" in the timing)

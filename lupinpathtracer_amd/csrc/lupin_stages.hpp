@@ -221,6 +221,12 @@ __global__ void __launch_bounds__(LP_BLOCK) k_begin(const FrameParams *__restric
 #ifndef LP_LIGHT_PDF_WAVES
 #define LP_LIGHT_PDF_WAVES 4
 #endif
+#ifndef LP_LIGHT_PDF_MIS_WAVES
+#define LP_LIGHT_PDF_MIS_WAVES 3
+#endif
+#ifndef LP_MIS_DEFER_SHADE_WAVES
+#define LP_MIS_DEFER_SHADE_WAVES 2
+#endif
 #ifndef LP_SIMPLE_SHADE_WAVES
 #define LP_SIMPLE_SHADE_WAVES 4
 #endif
@@ -630,7 +636,8 @@ template <int TYPE, typename Geo, bool SIMPLE = false, bool DEFER = false>
 __device__ __forceinline__ bool integrate_vertex(const Geo &geo, const SceneDev &sc, uint32_t *stack, const FrameParams &fp, PathRegs &p,
                                  float4 hitrec, uint32_t hit_tri, ShadowRays &sh)
 {
-    static_assert(!DEFER || TYPE == LUPIN_PATHTRACE_STANDARD, "the light-pdf stage serves the Standard integrator");
+    static_assert(!DEFER || TYPE == LUPIN_PATHTRACE_STANDARD || TYPE == LUPIN_PATHTRACE_MIS, "the light-pdf stage serves the Standard and MIS integrators");
+    constexpr bool DEFER_WEIGHT = DEFER && TYPE == LUPIN_PATHTRACE_STANDARD;   // MIS defers the two shadow-ray weights instead (below)
     const float eps = fp.pc.ray_epsilon;
     const uint32_t hit_inst = __float_as_uint(hitrec.w);
     p.pending = false;
@@ -701,7 +708,7 @@ __device__ __forceinline__ bool integrate_vertex(const Geo &geo, const SceneDev 
                 }
                 else incoming = lights_sample(sc, hit_pos, p.rng);
                 if (is_zero3(incoming)) return false;
-                if (DEFER)
+                if (DEFER_WEIGHT)
                 {
                     p.pend_bp = bsdf_pdf(mp, normal, outgoing, incoming);
                     p.pend_f = bsdf_eval(mp, normal, outgoing, incoming);
@@ -739,6 +746,18 @@ __device__ __forceinline__ bool integrate_vertex(const Geo &geo, const SceneDev 
                     if (!light_turn) incoming = mi;
 
                     f3 bsdfcos = bsdf_eval(mp, normal, outgoing, mi);
+                    if (DEFER)
+                    {
+                        // k_light_pdf_mis turns the BSDF pdf parked in the scalar into the MIS weight (or drops the ray)
+                        if (none_zero3(bsdfcos))
+                        {
+                            const float bp = bsdf_pdf(mp, normal, outgoing, mi);
+                            sh.org = hit_pos;
+                            if (!light_turn) { sh.d0 = mi; sh.f0 = mul(p.weight, bsdfcos); sh.s0 = bp; sh.v0 = true; }
+                            else             { sh.d1 = mi; sh.f1 = mul(p.weight, bsdfcos); sh.s1 = bp; sh.v1 = true; }
+                        }
+                        continue;
+                    }
                     float light_pdf = lights_pdf(geo, sc, stack, hit_pos, mi, eps);
                     float b_pdf = bsdf_pdf(mp, normal, outgoing, mi);
                     float mis_w;
@@ -802,7 +821,7 @@ __device__ __forceinline__ bool integrate_vertex(const Geo &geo, const SceneDev 
             else incoming = lights_sample(sc, hit_pos, p.rng);
             if (TYPE == LUPIN_PATHTRACE_MIS) p.next_emission = true;
             if (is_zero3(incoming)) return false;
-            if (DEFER)
+            if (DEFER_WEIGHT)
             {
                 p.pend_bp = phase_pdf(p.medium, outgoing, incoming);
                 p.pend_f = phase_eval(p.medium, outgoing, incoming);
@@ -818,7 +837,7 @@ __device__ __forceinline__ bool integrate_vertex(const Geo &geo, const SceneDev 
 
     p.ori = hit_pos;
     p.dir = incoming;
-    if (DEFER && p.pending) return true;
+    if (DEFER_WEIGHT && p.pending) return true;
     return weight_checks_and_roulette(p);
 }
 
@@ -1000,7 +1019,7 @@ __device__ __forceinline__ bool light_pdf_path(const Geo &geo, const SceneDev &s
 // k_shade in which those facts are compile-time constants: same arithmetic on the paths that exist, none of the code
 // for the ones that cannot.
 template <int TYPE, bool LDSGEO, bool SIMPLE, bool DEFER = false>
-__global__ void __attribute__((amdgpu_waves_per_eu(TYPE == 1 ? LP_MIS_SHADE_WAVES : (SIMPLE ? LP_SIMPLE_SHADE_WAVES : (DEFER ? LP_DEFER_SHADE_WAVES : LP_SHADE_WAVES)), 8))) __launch_bounds__(LP_BLOCK) k_shade(SceneDev sc, const FrameParams *__restrict__ fpp, PathBuffers pb, uint32_t iter,
+__global__ void __attribute__((amdgpu_waves_per_eu(TYPE == 1 ? (DEFER ? LP_MIS_DEFER_SHADE_WAVES : LP_MIS_SHADE_WAVES) : (SIMPLE ? LP_SIMPLE_SHADE_WAVES : (DEFER ? LP_DEFER_SHADE_WAVES : LP_SHADE_WAVES)), 8))) __launch_bounds__(LP_BLOCK) k_shade(SceneDev sc, const FrameParams *__restrict__ fpp, PathBuffers pb, uint32_t iter,
                                                     unsigned long long *shard_stats, uint32_t stack_words)
 {
     const FrameParams fp = *fpp;
@@ -1096,6 +1115,66 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LP_LIGHT_PDF_WAVES, 8))) __la
     __syncthreads();
     const bool alive = state == (uint32_t)SLOT_ALIVE || (waits && verdict[threadIdx.x] != 0u);
     queue_append(alive, slot, pb.queue[(iter + 1) & 1] + (size_t)shard * pb.shard_cap, &pb.counts[(iter + 1) * LP_SHARDS + shard]);
+}
+
+// Light-pdf stage of the MIS integrator: k_shade<MIS, DEFER> records up to two shadow-ray candidates per vertex with the
+// BSDF pdf in the scalar; this pass computes sample_lights_pdf for each (pathtracer.wgsl:2516-2549), the power-heuristic
+// weight (:822-829), and keeps the ray only if the weight is non-zero -- the reference's condition.  The block's
+// candidates (<= 512) are compacted so that whole waves march.
+template <bool LDSGEO>
+__global__ void __attribute__((amdgpu_waves_per_eu(LP_LIGHT_PDF_MIS_WAVES, 8))) __launch_bounds__(LP_BLOCK) k_light_pdf_mis(SceneDev sc, const FrameParams *__restrict__ fpp, PathBuffers pb, uint32_t iter, uint32_t stack_words)
+{
+    const FrameParams fp = *fpp;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+    __shared__ uint32_t items[2 * LP_BLOCK];      // compacted: 2 * thread index of the entry + ray
+    __shared__ uint32_t entry_slot[LP_BLOCK], entry_flags[LP_BLOCK];
+    __shared__ uint32_t wave_total[LP_BLOCK / 64];
+    const auto geo = make_geo<LDSGEO>(sc, lds_stack, stack_words);
+    const uint32_t shard = blockIdx.x % LP_SHARDS;
+    const uint32_t count = pb.counts[iter * LP_SHARDS + shard];
+    const uint32_t i = (blockIdx.x / LP_SHARDS) * LP_BLOCK + threadIdx.x;
+    if ((blockIdx.x / LP_SHARDS) * LP_BLOCK >= count) return;   // block-uniform
+    uint32_t slot = 0, flags = 0;
+    if (i < count)
+    {
+        slot = pb.queue[iter & 1][(size_t)shard * pb.shard_cap + i];
+        flags = __float_as_uint(pb.sh_org[slot].w) & 3u;
+    }
+    entry_slot[threadIdx.x] = slot;
+    entry_flags[threadIdx.x] = flags;
+    const uint32_t mine = (flags & 1u) + (flags >> 1);
+    // block-wide exclusive prefix of `mine`
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t incl = mine;
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, off); if ((int)lane >= off) incl += v; }
+    if (lane == 63) wave_total[wave] = incl;
+    __syncthreads();
+    uint32_t before = incl - mine, total = 0;
+    for (uint32_t w = 0; w < LP_BLOCK / 64; w++) { const uint32_t c = wave_total[w]; if (w < wave) before += c; total += c; }
+    if (flags & 1u) items[before] = 2u * threadIdx.x;
+    if (flags & 2u) items[before + (flags & 1u)] = 2u * threadIdx.x + 1u;
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < total; j += LP_BLOCK)
+    {
+        const uint32_t it = items[j], t = it >> 1, k = it & 1u;
+        const uint32_t s = entry_slot[t];
+        const float4 so = pb.sh_org[s];
+        float4 *rec = (k ? pb.sh_d1 : pb.sh_d0) + s;
+        const float4 dd = *rec;
+        const float light_pdf = lights_pdf(geo, sc, lds_stack, mk3(so.x, so.y, so.z), mk3(dd.x, dd.y, dd.z), fp.pc.ray_epsilon);
+        const float b_pdf = dd.w;
+        float mis_w;
+        if (k) mis_w = (light_pdf * light_pdf) / (light_pdf * light_pdf + b_pdf * b_pdf) / light_pdf;
+        else   mis_w = (b_pdf * b_pdf) / (b_pdf * b_pdf + light_pdf * light_pdf) / b_pdf;
+        if (mis_w != 0.0f) rec->w = mis_w;
+        else atomicAnd(&entry_flags[t], ~(1u << k));
+    }
+    __syncthreads();
+    if (entry_flags[threadIdx.x] != flags)
+    {
+        const float4 so = pb.sh_org[slot];
+        pb.sh_org[slot] = make_float4(so.x, so.y, so.z, __uint_as_float(entry_flags[threadIdx.x]));
+    }
 }
 
 // emission of a surface point: emission_sample * mat.emission of get_material_point (pathtracer.wgsl:1295-1298,1315)

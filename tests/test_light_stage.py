@@ -1,6 +1,7 @@
-"""Light-pdf stage (LUPIN_LIGHT_STAGE=1, k_light_pdf): sample_lights_pdf of the Standard integrator (pathtracer.wgsl:2516-2549 ->
-bvh_custom.wgsl:112-152) runs in its own stage between k_shade and the next extend.  Same draws, same arithmetic: the image
-equals the inline build's word for word and the oracle's."""
+"""Light-pdf stage (LUPIN_LIGHT_STAGE=1): sample_lights_pdf (pathtracer.wgsl:2516-2549 -> bvh_custom.wgsl:112-152) runs in its own
+stage -- k_light_pdf between k_shade and the next extend for the Standard integrator (weight update, roulette, epilogue),
+k_light_pdf_mis between k_shade and the shadow rays for MIS (the two power-heuristic weights).  Same draws, same arithmetic:
+the image equals the inline build's word for word and the oracle's."""
 import os
 
 import numpy as np
@@ -29,14 +30,15 @@ def staged_ctx(built):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,cam,bounces", [("arealights1", 0, 8), ("environments1", 0, 8), ("materials4", 0, 12), ("materials2", 0, 8),
                                               ("features1", 0, 8), ("bistro_class_small", 0, 16), ("cornellbox_builtin", 0, 8)])
-def test_stage_equals_inline_and_oracle(gpu_ctx, staged_ctx, name, cam, bounces):
+@pytest.mark.parametrize("ptype", [0, 1], ids=["standard", "mis"])
+def test_stage_equals_inline_and_oracle(gpu_ctx, staged_ctx, name, cam, bounces, ptype):
     inline_scene, cams = util.load_scene(name, gpu_ctx)
     staged_scene, _ = util.load_scene(name, staged_ctx)
     W, H = 200, 120
-    a = util.gpu_accumulate(gpu_ctx, inline_scene, cams[cam], W, H, frames=2, spp=3, max_bounces=bounces)
-    b = util.gpu_accumulate(staged_ctx, staged_scene, cams[cam], W, H, frames=2, spp=3, max_bounces=bounces)
+    a = util.gpu_accumulate(gpu_ctx, inline_scene, cams[cam], W, H, frames=2, spp=3, max_bounces=bounces, ptype=ptype)
+    b = util.gpu_accumulate(staged_ctx, staged_scene, cams[cam], W, H, frames=2, spp=3, max_bounces=bounces, ptype=ptype)
     assert util.f16_words_differ(a, b) == 0
-    ref = util.oracle_accumulate(staged_scene, cams[cam], W, H, frames=2, spp=3, max_bounces=bounces)
+    ref = util.oracle_accumulate(staged_scene, cams[cam], W, H, frames=2, spp=3, max_bounces=bounces, ptype=ptype)
     assert util.f16_words_differ(b, ref) == 0
 
 
