@@ -100,6 +100,22 @@ def pmc_record(workload_key):
         return json.load(f).get(workload_key, {})
 
 
+def request_ceiling():
+    """Random 64 / 128-byte record fetches per second the chip sustains, measured by tools/calib/gather_probe (profiles/): the
+    ceiling for a kernel whose loads are dependent gathers, in L1-miss requests per second."""
+    path = os.path.join(ROOT, "profiles", "r02_gather_probe.jsonl")
+    if not os.path.exists(path):
+        return None
+    best = 0.0
+    with open(path) as f:
+        for line in f:
+            if line.startswith("{"):
+                d = json.loads(line)
+                if d.get("stream") == "none" and d.get("record_bytes") in (64, 128):
+                    best = max(best, float(d["Grecords_per_s"]))
+    return best or None
+
+
 def measure_single_gpu(api, ctx, scene, cam, width, height, bounces, spp, steps, warmup, ptype, workload_key, peak_measured, keep_aspect=False):
     """Throughput + per-kernel roofline of one workload on one GPU (frames overlap as in production for `value`; the per-kernel
     pass runs them one at a time so that a duration belongs to one kernel)."""
@@ -161,6 +177,14 @@ def measure_single_gpu(api, ctx, scene, cam, width, height, bounces, spp, steps,
             "definition": "bytes REQUESTED by the closest-hit kernel in this build's layout after culling (64 B/node visit + 48 B/triangle "
                           "test + 64 B/instance entry + 56 B path state, device-counted) x units per launch / hipEvent launch time",
         }
+        l1_miss = pmc.get("counters_per_unit", {}).get("k_extend", {}).get("TCP_TCC_READ_REQ")
+        ceiling = request_ceiling()
+        if l1_miss and ceiling and not scene_is_lds_resident(scene):
+            greq = l1_miss * units_per_launch / avg_s / 1e9
+            rec["roofline"]["request_rate"] = {
+                "l1_miss_requests_per_unit": l1_miss, "achieved_Greq_per_s": greq, "ceiling_Greq_per_s": ceiling, "frac": greq / ceiling,
+                "definition": "TCP_TCC_READ_REQ per path-bounce (PMC pass in profiles/) x units per launch / launch time, against the rate of "
+                              "independent random 64- / 128-byte record fetches measured by tools/calib/gather_probe on this chip"}
         if scene_is_lds_resident(scene):
             rec["roofline"]["note"] = "geometry is staged in LDS (scene < 24 KB): requests are served on-chip, HBM is not the limiter here"
     return rec, res, params
