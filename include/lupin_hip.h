@@ -561,7 +561,7 @@ int64_t lupin_hip_build_bvh_device(LupinContext *ctx, const float *verts_pos4, u
  * partition, depth cap) from min / max / count reductions, so every node's box, split plane and triangle SET equals
  * lupin_build_bvh's bit for bit.  Only bookkeeping differs: nodes are numbered level by level and both sides of a
  * partition keep their input order.  Same signature and return value as lupin_build_bvh (out_nodes must not be NULL;
- * 2 * triangles - 1 nodes always suffice).  Synchronous. */
+ * 2 * triangles - 1 nodes always suffice; vertex positions must be finite).  Synchronous. */
 int64_t lupin_hip_build_bvh_sah_device(LupinContext *ctx, const float *verts_pos4, uint32_t num_verts, uint32_t *indices,
                                        uint32_t num_indices, LupinBvhNode *out_nodes, uint64_t out_capacity);
 

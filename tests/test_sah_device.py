@@ -83,6 +83,9 @@ def test_degenerate_inputs(gpu_ctx):
     bad = idx.copy(); bad[7] = 10_000
     with pytest.raises(api.LupinError):
         api.build_bvh_sah_device(gpu_ctx, verts, bad)
+    nan = verts.copy(); nan[5, 1] = np.nan       # ordered-integer min / max and fminf / fmaxf agree on finite values only: refused
+    with pytest.raises(api.LupinError):
+        api.build_bvh_sah_device(gpu_ctx, nan, idx)
 
 
 @pytest.mark.gpu
