@@ -461,7 +461,8 @@ def single_gpu_extras(args, api, ctx, scene, cam, cam_params, W, H, ptype):
     if not args.no_secondary and args.scene == "bistro_class":
         extras["configs"] = []
         for name, scene_name, w, h, bounces, steps, warm, aspect_keep in (("configs[1] cornellbox 1024x1024 b8", "cornellbox", 1024, 1024, 8, 64, 8, True),
-                                                                         ("configs[2] materials1 1920x1080 b12", "materials1", 1920, 1080, 12, 24, 4, False)):
+                                                                         ("configs[2] materials1 1920x1080 b12", "materials1", 1920, 1080, 12, 24, 4, False),
+                                                                         ("configs[3] environments1 1920x1080 b16", "environments1", 1920, 1080, 16, 24, 4, False)):
             sc2, cams2 = load_workload(scene_name, ctx)
             key = f"{scene_name}_{w}x{h}_b{bounces}_spp{args.spp}_standard"
             if args.no_kernel_timing:

@@ -40,4 +40,5 @@ profile_workload() {  # key, bench args...
 profile_workload bistro_class_3840x2160_b16_spp8_standard
 profile_workload cornellbox_1024x1024_b8_spp8_standard --scene cornellbox --width 1024 --height 1024 --bounces 8
 profile_workload materials1_1920x1080_b12_spp8_standard --scene materials1 --width 1920 --height 1080 --bounces 12
+profile_workload environments1_1920x1080_b16_spp8_standard --scene environments1 --width 1920 --height 1080 --bounces 16
 cat gpurun_out/${TAG}_bench.json | cut -c1-400
