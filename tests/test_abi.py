@@ -113,3 +113,18 @@ def test_rust_shim_declares_only_header_symbols_with_matching_struct_sizes():
             total += size[m.group(1)] * int(m.group(2)) if m else size[ty.strip()]
         assert total == nbytes, (name, total, nbytes)
     assert C.sizeof(_abi.TonemapDescC) == 36 and C.sizeof(_abi.DebugVizDescC) == 16
+
+
+def test_library_asks_for_eight_hardware_queues_unless_the_host_chose(built):
+    """Frames in flight run on one HIP stream each; the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).
+    Loading the library sets the variable to 8 when it is unset and leaves a host's choice alone (checked in fresh processes)."""
+    import subprocess
+    import sys
+    code = ("import ctypes, os, sys; sys.path.insert(0, %r); from lupinpathtracer_amd import _abi; _abi.lib(); "
+            "g = ctypes.CDLL(None).getenv; g.restype = ctypes.c_char_p; print(g(b'GPU_MAX_HW_QUEUES').decode())") % ROOT
+    for preset, want in ((None, "8"), ("2", "2")):
+        env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+        if preset is not None:
+            env["GPU_MAX_HW_QUEUES"] = preset
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+        assert out.returncode == 0 and out.stdout.strip() == want, out.stdout + out.stderr
