@@ -320,6 +320,9 @@ int lupin_hip_device_count(void);
  * device (they run on alternating internal streams), but each call sees the textures exactly as the calls before it
  * left them; uploads, downloads, copies and lupin_hip_sync wait for everything submitted earlier. */
 int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx);
+/* Destroying a context twice is a no-op.  Textures, scenes and communicators may be destroyed after their context (their
+ * device memory is freed then); every other use of an object whose context is gone returns LUPIN_ERR_INVALID_ARGUMENT
+ * instead of touching freed memory. */
 void lupin_hip_destroy_context(LupinContext *ctx);
 /* device.poll(wait_indefinitely) (loader.rs:1692,1825) */
 int lupin_hip_sync(LupinContext *ctx);

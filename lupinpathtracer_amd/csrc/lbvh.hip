@@ -146,6 +146,7 @@ int64_t lupin_hip_build_bvh_device(LupinContext *ctx, const float *verts_pos4, u
     const uint32_t depth = lupin_hip_lbvh_depth(n);
     const uint64_t num_nodes = (2ull << depth) - 1;
     if (num_nodes > out_capacity) return lupin_internal_fail(LUPIN_ERR_INVALID_ARGUMENT, "node buffer too small (see lupin_hip_lbvh_node_count)");
+    if (!lupin_internal_ctx_alive(ctx)) return lupin_internal_fail(LUPIN_ERR_INVALID_ARGUMENT, "the context has been destroyed");
     if (hipSetDevice(lupin_internal_ctx_device(ctx)) != hipSuccess) return lupin_internal_fail(LUPIN_ERR_HIP, "hipSetDevice");
     hipStream_t st = lupin_internal_ctx_stream(ctx);
 

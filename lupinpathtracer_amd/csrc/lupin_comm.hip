@@ -65,6 +65,7 @@ Rccl *rccl()
 
 struct LupinComm
 {
+    int device = 0;            // the context's device ordinal (the communicator may outlive the context)
     LupinContext *ctx = nullptr;
     ncclComm_t comm = nullptr;
     bool owns_comm = true;
@@ -142,6 +143,7 @@ int lupin_hip_comm_get_unique_id(uint8_t *out_id)
 int lupin_hip_comm_init_rank(LupinContext *ctx, const uint8_t *id_bytes, uint32_t rank, uint32_t world, LupinComm **out_comm)
 {
     if (!ctx || !id_bytes || !out_comm || world == 0 || rank >= world) return COMM_FAIL(LUPIN_ERR_INVALID_ARGUMENT, "bad communicator arguments");
+    if (!lupin_internal_ctx_alive(ctx)) return COMM_FAIL(LUPIN_ERR_INVALID_ARGUMENT, "the context of this object has been destroyed");
     Rccl *R; int rc = need_rccl(&R); if (rc) return rc;
     HIP_TRY_C(hipSetDevice(lupin_internal_ctx_device(ctx)));
     ncclUniqueId id;
@@ -149,7 +151,7 @@ int lupin_hip_comm_init_rank(LupinContext *ctx, const uint8_t *id_bytes, uint32_
     ncclComm_t comm = nullptr;
     NCCL_TRY(R->CommInitRank(&comm, (int)world, id, (int)rank));
     LupinComm *c = new LupinComm();
-    c->ctx = ctx; c->comm = comm; c->rank = rank; c->world = world;
+    c->ctx = ctx; c->device = lupin_internal_ctx_device(ctx); c->comm = comm; c->rank = rank; c->world = world;
     *out_comm = c;
     return LUPIN_OK;
 }
@@ -157,9 +159,10 @@ int lupin_hip_comm_init_rank(LupinContext *ctx, const uint8_t *id_bytes, uint32_
 int lupin_hip_comm_from_nccl(LupinContext *ctx, void *nccl_comm, uint32_t rank, uint32_t world, LupinComm **out_comm)
 {
     if (!ctx || !nccl_comm || !out_comm || world == 0 || rank >= world) return COMM_FAIL(LUPIN_ERR_INVALID_ARGUMENT, "bad communicator arguments");
+    if (!lupin_internal_ctx_alive(ctx)) return COMM_FAIL(LUPIN_ERR_INVALID_ARGUMENT, "the context of this object has been destroyed");
     Rccl *R; int rc = need_rccl(&R); if (rc) return rc;
     LupinComm *c = new LupinComm();
-    c->ctx = ctx; c->comm = (ncclComm_t)nccl_comm; c->owns_comm = false; c->rank = rank; c->world = world;
+    c->ctx = ctx; c->device = lupin_internal_ctx_device(ctx); c->comm = (ncclComm_t)nccl_comm; c->owns_comm = false; c->rank = rank; c->world = world;
     *out_comm = c;
     return LUPIN_OK;
 }
@@ -172,6 +175,7 @@ int lupin_hip_comm_init_all(LupinContext *const *ctxs, uint32_t n, LupinComm **o
     for (uint32_t i = 0; i < n; i++)
     {
         if (!ctxs[i]) return COMM_FAIL(LUPIN_ERR_INVALID_ARGUMENT, "null context");
+        if (!lupin_internal_ctx_alive(ctxs[i])) return COMM_FAIL(LUPIN_ERR_INVALID_ARGUMENT, "the context of this object has been destroyed");
         devs[i] = lupin_internal_ctx_device(ctxs[i]);
         for (uint32_t k = 0; k < i; k++) if (devs[k] == devs[i]) return COMM_FAIL(LUPIN_ERR_INVALID_ARGUMENT, "one context per device");
     }
@@ -180,7 +184,7 @@ int lupin_hip_comm_init_all(LupinContext *const *ctxs, uint32_t n, LupinComm **o
     for (uint32_t i = 0; i < n; i++)
     {
         LupinComm *c = new LupinComm();
-        c->ctx = ctxs[i]; c->comm = comms[i]; c->rank = i; c->world = n;
+        c->ctx = ctxs[i]; c->device = devs[i]; c->comm = comms[i]; c->rank = i; c->world = n;
         out_comms[i] = c;
     }
     return LUPIN_OK;
@@ -189,8 +193,8 @@ int lupin_hip_comm_init_all(LupinContext *const *ctxs, uint32_t n, LupinComm **o
 void lupin_hip_comm_destroy(LupinComm *c)
 {
     if (!c) return;
-    hipSetDevice(lupin_internal_ctx_device(c->ctx));
-    lupin_internal_sync_all(c->ctx);
+    hipSetDevice(c->device);
+    if (lupin_internal_ctx_alive(c->ctx)) lupin_internal_sync_all(c->ctx);   // a destroyed context has drained its streams already
     Rccl *R = rccl();
     if (c->owns_comm && c->comm && R->handle) R->CommDestroy(c->comm);
     if (c->send) hipFree(c->send);
@@ -226,6 +230,7 @@ static int gather_enqueue(Rccl *R, LupinComm *c, LupinTexture *tex, uint32_t til
 int lupin_hip_gather_framebuffer(LupinComm *c, LupinTexture *tex, uint32_t tile_size)
 {
     if (!c || !tex || tile_size == 0) return COMM_FAIL(LUPIN_ERR_INVALID_ARGUMENT, "bad gather arguments");
+    if (!lupin_internal_ctx_alive(c->ctx)) return COMM_FAIL(LUPIN_ERR_INVALID_ARGUMENT, "the context of this object has been destroyed");
     Rccl *R; int rc = need_rccl(&R); if (rc) return rc;
     for (int stage = 0; stage < 3; stage++)
         if ((rc = gather_enqueue(R, c, tex, tile_size, stage))) return rc;
@@ -240,6 +245,7 @@ int lupin_hip_gather_framebuffer_all(LupinComm *const *comms, LupinTexture *cons
     for (uint32_t i = 0; i < n; i++)
     {
         if (!comms[i] || !texs[i]) return COMM_FAIL(LUPIN_ERR_INVALID_ARGUMENT, "null communicator / texture");
+        if (!lupin_internal_ctx_alive(comms[i]->ctx)) return COMM_FAIL(LUPIN_ERR_INVALID_ARGUMENT, "the context of this object has been destroyed");
         if (texs[i]->width != texs[0]->width || texs[i]->height != texs[0]->height) return COMM_FAIL(LUPIN_ERR_INVALID_ARGUMENT, "framebuffers differ in size");
         if ((rc = gather_enqueue(R, comms[i], texs[i], tile_size, 0))) return rc;
     }
@@ -256,6 +262,7 @@ int lupin_hip_gather_framebuffer_all(LupinComm *const *comms, LupinTexture *cons
 int lupin_hip_comm_allreduce_f64(LupinComm *c, double *inout, uint32_t n, uint32_t op)
 {
     if (!c || !inout || n == 0 || op > 1) return COMM_FAIL(LUPIN_ERR_INVALID_ARGUMENT, "bad all-reduce arguments");
+    if (!lupin_internal_ctx_alive(c->ctx)) return COMM_FAIL(LUPIN_ERR_INVALID_ARGUMENT, "the context of this object has been destroyed");
     Rccl *R; int rc = need_rccl(&R); if (rc) return rc;
     if ((rc = ensure_scratch(c, n))) return rc;
     if ((rc = lupin_internal_sync_all(c->ctx))) return rc;

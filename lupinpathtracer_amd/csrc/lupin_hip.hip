@@ -12,6 +12,8 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <set>
+#include <mutex>
 #include <algorithm>
 #include <atomic>
 
@@ -104,6 +106,7 @@ struct LupinDoubleBufferedTexture
 struct LupinScene
 {
     LupinContext *ctx;
+    int device = 0;                                 // the context's device ordinal (the scene may outlive the context)
     SceneDev dev{};
     std::vector<void *> allocations;
     uint32_t stack_entries = 1;
@@ -373,6 +376,19 @@ static hipError_t sync_all(LupinContext *ctx)
     return e;
 }
 
+// Handles outlive their context in host code that tears down in the wrong order (garbage-collected hosts do): every entry
+// point that reaches a context through a texture / scene / communicator checks this registry instead of dereferencing a
+// freed pointer.  (An address reused by a later context counts as alive again; its objects are then merely foreign.)
+static std::mutex g_live_mu;
+static std::set<const LupinContext *> g_live_contexts;
+static bool ctx_alive(const LupinContext *ctx)
+{
+    std::lock_guard<std::mutex> lock(g_live_mu);
+    return ctx && g_live_contexts.count(ctx) != 0;
+}
+#define CTX_ALIVE_TRY(c) do { if (!ctx_alive(c)) return fail(LUPIN_ERR_INVALID_ARGUMENT, "the context of this object has been destroyed"); } while (0)
+
+bool lupin_internal_ctx_alive(const LupinContext *ctx) { return ctx_alive(ctx); }
 int lupin_internal_fail(int code, const char *msg) { return fail(code, msg); }
 void lupin_internal_join_primary(LupinContext *ctx) { join_primary(ctx); }
 int lupin_internal_sync_all(LupinContext *ctx) { HIP_TRY(hipSetDevice(ctx->device)); HIP_TRY(sync_all(ctx)); return LUPIN_OK; }
@@ -423,6 +439,7 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
         return fail(LUPIN_ERR_HIP, std::string("two HIP runtimes are mapped into this process (") + ri.hip_runtime_paths +
                                    "): load liblupin_hip.so in a process that has not imported another copy (e.g. a PyTorch wheel's)");
     LupinContext *ctx = new LupinContext();
+    { std::lock_guard<std::mutex> lock(g_live_mu); g_live_contexts.insert(ctx); }
     ctx->device = device_ordinal;
     ctx->runtime_version = ri.runtime_hip_version;
     hipError_t e = hipSuccess;
@@ -484,6 +501,10 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
 void lupin_hip_destroy_context(LupinContext *ctx)
 {
     if (!ctx) return;
+    {
+        std::lock_guard<std::mutex> lock(g_live_mu);
+        if (!g_live_contexts.erase(ctx)) return;   // not ours, or destroyed already
+    }
     hipSetDevice(ctx->device);
     sync_all(ctx);
     for (int k = 0; k < LP_MAX_LANES; k++)
@@ -509,6 +530,7 @@ void lupin_hip_destroy_context(LupinContext *ctx)
 
 int lupin_hip_sync(LupinContext *ctx)
 {
+    CTX_ALIVE_TRY(ctx);
     if (!ctx) return fail(LUPIN_ERR_INVALID_ARGUMENT, "ctx is null");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(sync_all(ctx));
@@ -517,6 +539,7 @@ int lupin_hip_sync(LupinContext *ctx)
 
 int lupin_hip_set_f16_store_rounding(LupinContext *ctx, int mode)
 {
+    CTX_ALIVE_TRY(ctx);
     if (!ctx || (mode != 0 && mode != 1)) return fail(LUPIN_ERR_INVALID_ARGUMENT, "mode must be 0 (toward zero) or 1 (nearest even)");
     ctx->store_rounding = mode;
     return LUPIN_OK;
@@ -524,6 +547,7 @@ int lupin_hip_set_f16_store_rounding(LupinContext *ctx, int mode)
 
 int lupin_hip_set_accumulation_mode(LupinContext *ctx, int mode)
 {
+    CTX_ALIVE_TRY(ctx);
     if (!ctx || (mode != LUPIN_ACCUM_F16_RUNNING_AVERAGE && mode != LUPIN_ACCUM_F32)) return fail(LUPIN_ERR_INVALID_ARGUMENT, "unknown accumulation mode");
     ctx->accum_mode = mode;
     return LUPIN_OK;
@@ -531,6 +555,7 @@ int lupin_hip_set_accumulation_mode(LupinContext *ctx, int mode)
 
 int lupin_hip_build_pathtrace_resources(LupinContext *ctx, const LupinBakedPathtraceParams *params, LupinPathtraceResources **out_res)
 {
+    CTX_ALIVE_TRY(ctx);
     if (!ctx || !params || !out_res) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
     if (params->samples_per_pixel == 0 || params->samples_per_pixel > 0xFFFFu) return fail(LUPIN_ERR_INVALID_ARGUMENT, "samples_per_pixel must be in [1, 65535]");
     if (params->max_bounces >= META_BOUNCE_MASK) return fail(LUPIN_ERR_INVALID_ARGUMENT, "max_bounces must be < 4095");
@@ -546,6 +571,7 @@ void lupin_hip_destroy_pathtrace_resources(LupinPathtraceResources *res) { delet
 
 int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinScene **out_scene)
 {
+    CTX_ALIVE_TRY(ctx);
     if (!ctx || !desc || !out_scene) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
     HIP_TRY(hipSetDevice(ctx->device));
     const LupinSceneDesc &s = *desc;
@@ -588,6 +614,7 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
 
     LupinScene *sc = new LupinScene();
     sc->ctx = ctx;
+    sc->device = ctx->device;
     sc->instances_empty = s.num_instances == 0;
     sc->lights_empty = s.num_lights == 0;
     sc->envs_empty = s.num_environments == 0;
@@ -941,8 +968,8 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
 void lupin_hip_scene_destroy(LupinScene *scene)
 {
     if (!scene) return;
-    hipSetDevice(scene->ctx->device);
-    sync_all(scene->ctx);
+    hipSetDevice(scene->device);
+    if (ctx_alive(scene->ctx)) sync_all(scene->ctx);   // a destroyed context has drained its streams already
     for (void *p : scene->allocations) hipFree(p);
     delete scene;
 }
@@ -951,10 +978,11 @@ void lupin_hip_scene_destroy(LupinScene *scene)
 
 int lupin_hip_texture_create(LupinContext *ctx, uint32_t width, uint32_t height, LupinTexture **out_tex)
 {
+    CTX_ALIVE_TRY(ctx);
     if (!ctx || !out_tex || width == 0 || height == 0) return fail(LUPIN_ERR_INVALID_ARGUMENT, "bad texture size");
     HIP_TRY(hipSetDevice(ctx->device));
     LupinTexture *t = new LupinTexture();
-    t->ctx = ctx; t->width = width; t->height = height; t->data = nullptr; t->accum32 = nullptr; t->accum32_valid = false;
+    t->ctx = ctx; t->device = ctx->device; t->width = width; t->height = height; t->data = nullptr; t->accum32 = nullptr; t->accum32_valid = false;
     size_t bytes = (size_t)width * height * 4 * sizeof(__half);
     hipError_t e = hipMalloc((void **)&t->data, bytes);
     if (e != hipSuccess) { delete t; return fail(LUPIN_ERR_OUT_OF_MEMORY, hipGetErrorString(e)); }
@@ -965,8 +993,8 @@ int lupin_hip_texture_create(LupinContext *ctx, uint32_t width, uint32_t height,
 void lupin_hip_texture_destroy(LupinTexture *tex)
 {
     if (!tex) return;
-    hipSetDevice(tex->ctx->device);
-    sync_all(tex->ctx);
+    hipSetDevice(tex->device);
+    if (ctx_alive(tex->ctx)) sync_all(tex->ctx);
     hipFree(tex->data);
     if (tex->accum32) hipFree(tex->accum32);
     delete tex;
@@ -978,6 +1006,7 @@ void *lupin_hip_texture_device_ptr(const LupinTexture *tex) { return tex ? (void
 int lupin_hip_texture_upload_rgba16f(LupinTexture *tex, const uint16_t *pixels)
 {
     if (!tex || !pixels) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
+    CTX_ALIVE_TRY(tex->ctx);
     HIP_TRY(hipSetDevice(tex->ctx->device));
     join_primary(tex->ctx);
     HIP_TRY(hipMemcpyAsync(tex->data, pixels, (size_t)tex->width * tex->height * 8, hipMemcpyHostToDevice, tex->ctx->stream));
@@ -989,6 +1018,7 @@ int lupin_hip_texture_download_rgba32f(const LupinTexture *tex, float *out_pixel
 {
     if (!tex || !out_pixels) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
     if (!tex->accum32 || !tex->accum32_valid) return fail(LUPIN_ERR_INVALID_ARGUMENT, "texture has no f32 accumulator (render into it with LUPIN_ACCUM_F32 first)");
+    CTX_ALIVE_TRY(tex->ctx);
     HIP_TRY(hipSetDevice(tex->ctx->device));
     join_primary(tex->ctx);
     HIP_TRY(hipMemcpyAsync(out_pixels, tex->accum32, (size_t)tex->width * tex->height * 16, hipMemcpyDeviceToHost, tex->ctx->stream));
@@ -998,6 +1028,7 @@ int lupin_hip_texture_download_rgba32f(const LupinTexture *tex, float *out_pixel
 int lupin_hip_texture_download_rgba16f(const LupinTexture *tex, uint16_t *out_pixels)
 {
     if (!tex || !out_pixels) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
+    CTX_ALIVE_TRY(tex->ctx);
     HIP_TRY(hipSetDevice(tex->ctx->device));
     join_primary(tex->ctx);
     HIP_TRY(hipMemcpyAsync(out_pixels, tex->data, (size_t)tex->width * tex->height * 8, hipMemcpyDeviceToHost, tex->ctx->stream));
@@ -1007,6 +1038,7 @@ int lupin_hip_texture_download_rgba16f(const LupinTexture *tex, uint16_t *out_pi
 
 int lupin_hip_dbuf_create(LupinContext *ctx, uint32_t width, uint32_t height, LupinDoubleBufferedTexture **out)
 {
+    CTX_ALIVE_TRY(ctx);
     if (!out) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
     LupinDoubleBufferedTexture *d = new LupinDoubleBufferedTexture();
     d->ctx = ctx; d->tex[0] = d->tex[1] = nullptr; d->front_idx = 1; d->back_idx = 0;   // wgpu_utils.rs:293-298
@@ -1029,6 +1061,7 @@ int lupin_hip_dbuf_copy_front_to_back(LupinDoubleBufferedTexture *t)
 {
     if (!t) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
     LupinTexture *f = t->tex[t->front_idx], *b = t->tex[t->back_idx];
+    CTX_ALIVE_TRY(t->ctx);
     HIP_TRY(hipSetDevice(t->ctx->device));
     join_primary(t->ctx);
     HIP_TRY(hipMemcpyAsync(b->data, f->data, (size_t)f->width * f->height * 8, hipMemcpyDeviceToDevice, t->ctx->stream));
@@ -1047,6 +1080,7 @@ int lupin_hip_dbuf_resize(LupinDoubleBufferedTexture *t, uint32_t width, uint32_
     if (!t) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
     if (t->tex[0]->width == width && t->tex[0]->height == height) return LUPIN_OK;   // wgpu_utils.rs:343
     LupinTexture *a = nullptr, *b = nullptr;
+    CTX_ALIVE_TRY(t->ctx);
     int rc = lupin_hip_texture_create(t->ctx, width, height, &a);
     if (rc == LUPIN_OK) rc = lupin_hip_texture_create(t->ctx, width, height, &b);
     if (rc != LUPIN_OK) { lupin_hip_texture_destroy(a); return rc; }
@@ -1063,6 +1097,7 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
                           bool tile_set, uint32_t set_tile_size, uint32_t rank, uint32_t world, int falsecolor_type = -1,
                           const LupinDebugVizDesc *debug = nullptr)
 {
+    CTX_ALIVE_TRY(ctx);
     if (!ctx || !res || !scene || !render_target || !desc) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
     if (falsecolor_type < 0 && pathtrace_type > LUPIN_PATHTRACE_DIRECT) return fail(LUPIN_ERR_INVALID_ARGUMENT, "unknown pathtrace_type");
     if (falsecolor_type > 11) return fail(LUPIN_ERR_INVALID_ARGUMENT, "unknown falsecolor_type");
@@ -1301,6 +1336,7 @@ int lupin_hip_pathtrace_scene_tiles(LupinContext *ctx, const LupinPathtraceResou
 
 int lupin_hip_stats_reset(LupinContext *ctx, int enable_kernel_timing)
 {
+    CTX_ALIVE_TRY(ctx);
     if (!ctx) return fail(LUPIN_ERR_INVALID_ARGUMENT, "ctx is null");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(sync_all(ctx));
@@ -1323,6 +1359,7 @@ int lupin_hip_stats_reset(LupinContext *ctx, int enable_kernel_timing)
 
 int lupin_hip_stats_get(LupinContext *ctx, LupinStats *out)
 {
+    CTX_ALIVE_TRY(ctx);
     if (!ctx || !out) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(sync_all(ctx));
@@ -1353,6 +1390,7 @@ int lupin_hip_stats_get(LupinContext *ctx, LupinStats *out)
 
 int lupin_hip_measure_copy_bandwidth(LupinContext *ctx, uint64_t bytes, uint32_t reps, double *out_gb_per_s)
 {
+    CTX_ALIVE_TRY(ctx);
     if (!ctx || !out_gb_per_s || bytes < 16 || reps == 0) return fail(LUPIN_ERR_INVALID_ARGUMENT, "bad copy-bandwidth arguments");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(sync_all(ctx));
@@ -1412,6 +1450,7 @@ int lupin_hip_runtime_info(LupinRuntimeInfo *out)
 int lupin_hip_trace_rays(LupinContext *ctx, const LupinScene *scene, uint32_t n, const float *ori_xyz, const float *dir_xyz,
                          float ray_epsilon, uint32_t *out_hit, float *out_dst, float *out_uv, uint32_t *out_instance, uint32_t *out_tri)
 {
+    CTX_ALIVE_TRY(ctx);
     if (!ctx || !scene || !ori_xyz || !dir_xyz || !out_hit || !out_dst || !out_uv || !out_instance || !out_tri) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
     if (n == 0) return LUPIN_OK;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1441,6 +1480,7 @@ int lupin_hip_trace_rays(LupinContext *ctx, const LupinScene *scene, uint32_t n,
 
 int lupin_hip_detmath_probe(LupinContext *ctx, int fn, uint32_t n, const float *x, const float *y, float *out)
 {
+    CTX_ALIVE_TRY(ctx);
     if (!ctx || !x || !y || !out) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
     if (n == 0) return LUPIN_OK;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1464,18 +1504,21 @@ static int pack_common(LupinContext *ctx, const LupinTexture *tex, uint32_t tile
 }
 int lupin_hip_pack_tiles(LupinContext *ctx, const LupinTexture *tex, uint32_t tile_size, uint32_t rank, uint32_t world, void *device_dst, uint64_t *out_pixels)
 {
+    CTX_ALIVE_TRY(ctx);
     int rc = pack_common(ctx, tex, tile_size, rank, world, device_dst, 0);
     if (rc == LUPIN_OK && out_pixels) *out_pixels = lupin_hip_packed_tile_pixels(tex->width, tex->height, tile_size, rank, world);
     return rc;
 }
 int lupin_hip_unpack_tiles(LupinContext *ctx, LupinTexture *tex, uint32_t tile_size, uint32_t rank, uint32_t world, const void *device_src)
 {
+    CTX_ALIVE_TRY(ctx);
     return pack_common(ctx, tex, tile_size, rank, world, const_cast<void *>(device_src), 1);
 }
 
 int lupin_hip_unpack_gathered_tiles(LupinContext *ctx, LupinTexture *tex, uint32_t tile_size, uint32_t rank, uint32_t world,
                                     const void *device_gathered, uint64_t capacity_pixels)
 {
+    CTX_ALIVE_TRY(ctx);
     if (!ctx || !tex || !device_gathered || tile_size == 0 || world == 0 || rank >= world) return fail(LUPIN_ERR_INVALID_ARGUMENT, "bad unpack arguments");
     return lupin_internal_tiles_copy(ctx, tex, const_cast<void *>(device_gathered), tile_size, rank, world, capacity_pixels, 2);
 }
@@ -1483,6 +1526,7 @@ int lupin_hip_unpack_gathered_tiles(LupinContext *ctx, LupinTexture *tex, uint32
 int lupin_hip_tonemap_and_fit_aspect(LupinContext *ctx, const LupinTexture *src, uint8_t *dst_rgba8, uint32_t dst_width, uint32_t dst_height,
                                      const LupinTonemapDesc *desc)
 {
+    CTX_ALIVE_TRY(ctx);
     if (!ctx || !src || !dst_rgba8 || !desc || dst_width == 0 || dst_height == 0) return fail(LUPIN_ERR_INVALID_ARGUMENT, "bad tonemap arguments");
     HIP_TRY(hipSetDevice(ctx->device));
     TonemapArgs a;

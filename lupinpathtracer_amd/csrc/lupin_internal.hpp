@@ -7,6 +7,7 @@
 struct LupinTexture
 {
     LupinContext *ctx;
+    int device;            // the context's device ordinal (valid after the context is gone: a texture may outlive it)
     uint32_t width, height;
     __half *data;          // Rgba16Float, row-major, row 0 = top
     float4 *accum32;       // f32 shadow (LUPIN_ACCUM_F32), allocated by the first frame rendered into it in that mode
@@ -14,6 +15,7 @@ struct LupinTexture
 };
 
 int lupin_internal_fail(int code, const char *msg);          // records the message lupin_hip_last_error() returns
+bool lupin_internal_ctx_alive(const LupinContext *ctx);       // created by lupin_hip_create_context and not destroyed since
 int lupin_internal_ctx_device(const LupinContext *ctx);
 hipStream_t lupin_internal_ctx_stream(const LupinContext *ctx);   // the primary stream
 void lupin_internal_join_primary(LupinContext *ctx);         // primary stream waits for the frames enqueued so far

@@ -355,6 +355,7 @@ int64_t lupin_hip_build_bvh_sah_device(LupinContext *ctx, const float *verts_pos
     // min / max run on order-preserving integers here and through fminf / fmaxf on the CPU: they agree on finite values only
     for (size_t i = 0; i < (size_t)num_verts * 4; i++)
         if ((i & 3) != 3 && !std::isfinite(verts_pos4[i])) return lupin_internal_fail(LUPIN_ERR_INVALID_ARGUMENT, "non-finite vertex position (use lupin_build_bvh)");
+    if (!lupin_internal_ctx_alive(ctx)) return lupin_internal_fail(LUPIN_ERR_INVALID_ARGUMENT, "the context has been destroyed");
     if (hipSetDevice(lupin_internal_ctx_device(ctx)) != hipSuccess) return lupin_internal_fail(LUPIN_ERR_HIP, "hipSetDevice");
     hipStream_t st = lupin_internal_ctx_stream(ctx);
     const uint64_t max_nodes = 2ull * n - 1ull;

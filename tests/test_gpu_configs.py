@@ -177,3 +177,29 @@ def test_measured_copy_bandwidth_and_runtime(gpu_ctx):
     info = api.runtime_info()
     assert info["num_hip_runtimes_mapped"] == 1
     assert info["build_hip_version"] // 100000 == info["runtime_hip_version"] // 100000
+
+
+@pytest.mark.gpu
+def test_objects_that_outlive_their_context_fail_cleanly(built):
+    """Hosts that tear down in the wrong order (or a garbage collector) hand stale handles to the C side: it answers with an error,
+    frees what it can and never dereferences the dead context."""
+    import ctypes as C
+    from lupinpathtracer_amd import _abi
+    lib = _abi.lib()
+    ctx = C.c_void_p()
+    assert lib.lupin_hip_create_context(0, C.byref(ctx)) == 0
+    tex, dbuf = C.c_void_p(), C.c_void_p()
+    assert lib.lupin_hip_texture_create(ctx, 64, 32, C.byref(tex)) == 0
+    assert lib.lupin_hip_dbuf_create(ctx, 64, 32, C.byref(dbuf)) == 0
+    lib.lupin_hip_destroy_context(ctx)
+    lib.lupin_hip_destroy_context(ctx)                                   # twice: the second call is a no-op
+    buf = np.zeros((32, 64, 4), np.uint16)
+    assert lib.lupin_hip_texture_download_rgba16f(tex, buf.ctypes.data_as(C.c_void_p)) != 0
+    assert b"destroyed" in lib.lupin_hip_last_error()
+    assert lib.lupin_hip_texture_upload_rgba16f(tex, buf.ctypes.data_as(C.c_void_p)) != 0
+    assert lib.lupin_hip_dbuf_copy_front_to_back(dbuf) != 0
+    assert lib.lupin_hip_sync(ctx) != 0
+    other = C.c_void_p()
+    assert lib.lupin_hip_texture_create(ctx, 8, 8, C.byref(other)) != 0
+    lib.lupin_hip_texture_destroy(tex)                                   # frees the device memory, no sync on the dead context
+    lib.lupin_hip_dbuf_destroy(dbuf)
