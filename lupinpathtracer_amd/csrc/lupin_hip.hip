@@ -70,6 +70,7 @@ struct LupinContext
     int last_lane = -1;
     hipEvent_t marker = nullptr;
     bool timing = false;
+    bool sort_window = true;        // LUPIN_SORT_WINDOW=0: k_shade sorts its own 256 paths instead of the k_sort_queue pass
     int light_stage = 0;            // LUPIN_LIGHT_STAGE=1: sample_lights_pdf in its own stage (k_light_pdf) instead of inline in k_shade
     bool debug_sync = false;        // LUPIN_DEBUG_SYNC=1: synchronise and report after every stage launch (fault localisation)
     bool counting = false;          // lupin_hip_stats_reset(ctx, 2): the tracing kernels run their work-counting instantiation
@@ -280,10 +281,18 @@ static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *sc
     }
     bool light_stage = false;
     if constexpr (TYPE == LUPIN_PATHTRACE_STANDARD || TYPE == LUPIN_PATHTRACE_MIS) light_stage = use_light_stage(ctx, scene);
+    // several material families: sort the queue in windows first, k_shade then finds its 256 paths (nearly) uniform
+    SceneDev shade_dev = scene->dev;
+    if (scene->dev.sort_shade && ctx->sort_window)
+    {
+        const uint32_t windows = ((blocks / LP_SHARDS) * LP_BLOCK + LP_SORT_WINDOW - 1) / LP_SORT_WINDOW;
+        hipLaunchKernelGGL(k_sort_queue, dim3(windows * LP_SHARDS), dim3(LP_BLOCK), 0, st, scene->dev, ln->pb, iter);
+        shade_dev.sort_shade = 0;
+    }
     if (scene->simple_matte && ctx->specialize_simple)
-        hipLaunchKernelGGL((k_shade<TYPE, LDSGEO, true>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
+        hipLaunchKernelGGL((k_shade<TYPE, LDSGEO, true>), dim3(blocks), dim3(LP_BLOCK), lds, st, shade_dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
     else if (!light_stage)
-        hipLaunchKernelGGL((k_shade<TYPE, LDSGEO, false>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
+        hipLaunchKernelGGL((k_shade<TYPE, LDSGEO, false>), dim3(blocks), dim3(LP_BLOCK), lds, st, shade_dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
     if constexpr (TYPE == LUPIN_PATHTRACE_STANDARD)
     {
         if (light_stage)
@@ -291,7 +300,7 @@ static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *sc
             // sample_lights_pdf has its own stage: k_shade tags the vertices that need it, k_light_pdf finishes them and appends
             // (this k_shade never traverses: without LDS-staged geometry it needs the block sort's 256 words only)
             const size_t shade_lds = LDSGEO ? lds : std::min(lds, (size_t)LP_BLOCK * sizeof(uint32_t));
-            hipLaunchKernelGGL((k_shade<TYPE, LDSGEO, false, true>), dim3(blocks), dim3(LP_BLOCK), shade_lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
+            hipLaunchKernelGGL((k_shade<TYPE, LDSGEO, false, true>), dim3(blocks), dim3(LP_BLOCK), shade_lds, st, shade_dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
             hipLaunchKernelGGL((k_light_pdf<TYPE, LDSGEO>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, stack_words);
         }
     }
@@ -300,7 +309,7 @@ static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *sc
         if (light_stage)
         {
             // the two MIS weights per vertex need sample_lights_pdf: k_shade parks the candidates, this pass weighs them
-            hipLaunchKernelGGL((k_shade<TYPE, LDSGEO, false, true>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
+            hipLaunchKernelGGL((k_shade<TYPE, LDSGEO, false, true>), dim3(blocks), dim3(LP_BLOCK), lds, st, shade_dev, fp, ln->pb, iter, ln->stat_counters, stack_words);
             hipLaunchKernelGGL((k_light_pdf_mis<LDSGEO>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, stack_words);
         }
     }
@@ -476,6 +485,7 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
     const char *dbs = getenv("LUPIN_DEBUG_SYNC");
     ctx->debug_sync = dbs && strcmp(dbs, "0") != 0;
     if (const char *lsg = getenv("LUPIN_LIGHT_STAGE")) ctx->light_stage = atoi(lsg) != 0 ? 1 : 0;
+    if (const char *sw = getenv("LUPIN_SORT_WINDOW")) ctx->sort_window = atoi(sw) != 0;
     const char *ssh = getenv("LUPIN_SIMPLE_SHADE");
     if (ssh && strcmp(ssh, "0") == 0) ctx->specialize_simple = false;
     const char *gr = getenv("LUPIN_GRAPH");

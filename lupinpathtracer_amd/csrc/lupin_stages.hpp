@@ -1015,6 +1015,62 @@ __device__ __forceinline__ bool light_pdf_path(const Geo &geo, const SceneDev &s
     return path_epilogue<TYPE>(fp, pb, slot, p, sample, cont, false, r4);
 }
 
+// Scenes with several material families: before k_shade, each window of LP_SORT_WINDOW queue entries is counting-sorted in place
+// by what the path will execute (material type of the hit | miss | inside a medium), so that a k_shade wave runs one BSDF
+// family instead of several (a 256-path window inside k_shade left two or three per wave).  Which queue position holds which
+// path does not matter: all path state lives in the path's slot.
+#ifndef LP_SORT_WINDOW
+#define LP_SORT_WINDOW 4096
+#endif
+__global__ void __launch_bounds__(LP_BLOCK) k_sort_queue(SceneDev sc, PathBuffers pb, uint32_t iter)
+{
+    constexpr uint32_t PER_THREAD = LP_SORT_WINDOW / LP_BLOCK;
+    __shared__ uint32_t sorted[LP_SORT_WINDOW];
+    __shared__ uint32_t bins[16];
+    const uint32_t shard = blockIdx.x % LP_SHARDS;
+    const uint32_t count = pb.counts[iter * LP_SHARDS + shard];
+    const uint32_t base_i = (blockIdx.x / LP_SHARDS) * LP_SORT_WINDOW;
+    if (base_i >= count) return;   // block-uniform
+    uint32_t *entries = pb.queue[iter & 1] + (size_t)shard * pb.shard_cap + base_i;
+    const uint32_t valid = min(LP_SORT_WINDOW, count - base_i);
+    if (threadIdx.x < 16) bins[threadIdx.x] = 0u;
+    __syncthreads();
+    uint32_t my_slot[PER_THREAD], my_key[PER_THREAD], my_rank[PER_THREAD];
+    #pragma unroll
+    for (uint32_t r = 0; r < PER_THREAD; r++)
+    {
+        const uint32_t j = r * LP_BLOCK + threadIdx.x;
+        my_key[r] = 15u; my_slot[r] = 0u; my_rank[r] = 0u;
+        if (j < valid)
+        {
+            my_slot[r] = entries[j];
+            const uint32_t inst = __float_as_uint(pb.hit[my_slot[r]].w);
+            const uint32_t meta = __float_as_uint(pb.dir_meta[my_slot[r]].w);
+            my_key[r] = (meta & META_VOLUME) ? 9u : (inst == HIT_MISS ? 8u : ((sc.instances[inst].flags >> 8) & 7u));
+            my_rank[r] = atomicAdd(&bins[my_key[r]], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t start[16];
+    { uint32_t acc = 0; for (uint32_t k = 0; k < 16; k++) { start[k] = acc; acc += bins[k]; } }
+    #pragma unroll
+    for (uint32_t r = 0; r < PER_THREAD; r++)
+        if (r * LP_BLOCK + threadIdx.x < valid)
+        {
+            uint32_t before = 0;
+            #pragma unroll
+            for (uint32_t k = 0; k < 10; k++) before = (k == my_key[r]) ? start[k] : before;
+            sorted[before + my_rank[r]] = my_slot[r];
+        }
+    __syncthreads();
+    #pragma unroll
+    for (uint32_t r = 0; r < PER_THREAD; r++)
+    {
+        const uint32_t j = r * LP_BLOCK + threadIdx.x;
+        if (j < valid) entries[j] = sorted[j];
+    }
+}
+
 // SIMPLE: scenes of untextured matte surfaces without environments (LupinScene::simple_matte, decided at upload) get a
 // k_shade in which those facts are compile-time constants: same arithmetic on the paths that exist, none of the code
 // for the ones that cannot.
