@@ -286,7 +286,7 @@ static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *sc
     if (scene->dev.sort_shade && ctx->sort_window)
     {
         const uint32_t windows = ((blocks / LP_SHARDS) * LP_BLOCK + LP_SORT_WINDOW - 1) / LP_SORT_WINDOW;
-        hipLaunchKernelGGL(k_sort_queue, dim3(windows * LP_SHARDS), dim3(LP_BLOCK), 0, st, scene->dev, ln->pb, iter);
+        hipLaunchKernelGGL(k_sort_queue<TYPE == LUPIN_PATHTRACE_STANDARD>, dim3(windows * LP_SHARDS), dim3(LP_BLOCK), 0, st, scene->dev, ln->pb, iter);
         shade_dev.sort_shade = 0;
     }
     if (scene->simple_matte && ctx->specialize_simple)
@@ -820,7 +820,10 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
                            (mat.color_tex_idx != LUPIN_SENTINEL_IDX && meshes[in.mesh_idx].texcoords_base != LUPIN_SENTINEL_IDX) ||
                            meshes[in.mesh_idx].colors_base != LUPIN_SENTINEL_IDX;
         any_alpha = any_alpha || maybe_alpha;
-        d.flags = (maybe_alpha ? 1u : 0u) | ((mat.mat_type & 0xFu) << 8);   // bits 8..11: material type = k_shade's sort key
+        // bits 8..11: material type, bit 12: the material's own roughness is zero (a hint: smooth reflective / refractive /
+        // transparent surfaces take the delta branch unless a roughness texture says otherwise) = k_sort_queue's key
+        const bool smooth = mat.roughness == 0.0f && (mat.mat_type == LUPIN_MAT_REFLECTIVE || mat.mat_type == LUPIN_MAT_REFRACTIVE || mat.mat_type == LUPIN_MAT_TRANSPARENT);
+        d.flags = (maybe_alpha ? 1u : 0u) | ((mat.mat_type & 0xFu) << 8) | (smooth ? 1u << 12 : 0u);
         mat_types_seen |= 1u << (mat.mat_type & 0xFu);
         instances[i] = d;
     }

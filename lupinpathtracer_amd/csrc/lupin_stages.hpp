@@ -1022,46 +1022,66 @@ __device__ __forceinline__ bool light_pdf_path(const Geo &geo, const SceneDev &s
 #ifndef LP_SORT_WINDOW
 #define LP_SORT_WINDOW 4096
 #endif
+// Key: material type of the hit (0..7) | miss (8) | inside a medium (9), then two more bits where they separate code paths:
+// the material's smooth hint (delta branch), and -- PEEK_COIN, Standard integrator -- the outcome of the path's next random
+// number, which for a surface hit outside a medium is the BSDF-or-light-sampling coin (pathtracer.wgsl:640-642): a wave then
+// runs one of the two samplers instead of both.  The path's RNG state is read, not advanced.
+template <bool PEEK_COIN>
 __global__ void __launch_bounds__(LP_BLOCK) k_sort_queue(SceneDev sc, PathBuffers pb, uint32_t iter)
 {
     constexpr uint32_t PER_THREAD = LP_SORT_WINDOW / LP_BLOCK;
+    constexpr uint32_t NUM_KEYS = 64;
     __shared__ uint32_t sorted[LP_SORT_WINDOW];
-    __shared__ uint32_t bins[16];
+    __shared__ uint32_t bins[NUM_KEYS];
     const uint32_t shard = blockIdx.x % LP_SHARDS;
     const uint32_t count = pb.counts[iter * LP_SHARDS + shard];
     const uint32_t base_i = (blockIdx.x / LP_SHARDS) * LP_SORT_WINDOW;
     if (base_i >= count) return;   // block-uniform
     uint32_t *entries = pb.queue[iter & 1] + (size_t)shard * pb.shard_cap + base_i;
     const uint32_t valid = min(LP_SORT_WINDOW, count - base_i);
-    if (threadIdx.x < 16) bins[threadIdx.x] = 0u;
+    if (threadIdx.x < NUM_KEYS) bins[threadIdx.x] = 0u;
     __syncthreads();
     uint32_t my_slot[PER_THREAD], my_key[PER_THREAD], my_rank[PER_THREAD];
     #pragma unroll
     for (uint32_t r = 0; r < PER_THREAD; r++)
     {
         const uint32_t j = r * LP_BLOCK + threadIdx.x;
-        my_key[r] = 15u; my_slot[r] = 0u; my_rank[r] = 0u;
+        my_key[r] = NUM_KEYS - 1u; my_slot[r] = 0u; my_rank[r] = 0u;
         if (j < valid)
         {
             my_slot[r] = entries[j];
             const uint32_t inst = __float_as_uint(pb.hit[my_slot[r]].w);
             const uint32_t meta = __float_as_uint(pb.dir_meta[my_slot[r]].w);
-            my_key[r] = (meta & META_VOLUME) ? 9u : (inst == HIT_MISS ? 8u : ((sc.instances[inst].flags >> 8) & 7u));
-            my_rank[r] = atomicAdd(&bins[my_key[r]], 1u);
+            uint32_t key;
+            if (meta & META_VOLUME) key = 9u;
+            else if (inst == HIT_MISS) key = 8u;
+            else
+            {
+                const uint32_t fl = sc.instances[inst].flags;
+                key = (fl >> 8) & 7u;
+                if (fl & (1u << 12)) key |= 16u;
+                else if (PEEK_COIN)
+                {
+                    uint32_t rng = __float_as_uint(pb.ori_rng[my_slot[r]].w);
+                    if (rnd(rng) < 0.5f) key |= 32u;
+                }
+            }
+            my_key[r] = key;
+            my_rank[r] = atomicAdd(&bins[key], 1u);
         }
     }
     __syncthreads();
-    uint32_t start[16];
-    { uint32_t acc = 0; for (uint32_t k = 0; k < 16; k++) { start[k] = acc; acc += bins[k]; } }
+    if (threadIdx.x < 64)   // exclusive prefix of the 64 bins by the first wave
+    {
+        const uint32_t c = bins[threadIdx.x];
+        uint32_t incl = c;
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, off); if ((int)threadIdx.x >= off) incl += v; }
+        bins[threadIdx.x] = incl - c;
+    }
+    __syncthreads();
     #pragma unroll
     for (uint32_t r = 0; r < PER_THREAD; r++)
-        if (r * LP_BLOCK + threadIdx.x < valid)
-        {
-            uint32_t before = 0;
-            #pragma unroll
-            for (uint32_t k = 0; k < 10; k++) before = (k == my_key[r]) ? start[k] : before;
-            sorted[before + my_rank[r]] = my_slot[r];
-        }
+        if (r * LP_BLOCK + threadIdx.x < valid) sorted[bins[my_key[r]] + my_rank[r]] = my_slot[r];
     __syncthreads();
     #pragma unroll
     for (uint32_t r = 0; r < PER_THREAD; r++)
