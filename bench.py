@@ -181,11 +181,11 @@ def measure_single_gpu(api, ctx, scene, cam, width, height, bounces, spp, steps,
         ceiling = request_ceiling()
         if l1_miss and ceiling and not scene_is_lds_resident(scene):
             greq = l1_miss * units_per_launch / avg_s / 1e9
-            shade_miss = pmc.get("counters_per_unit", {}).get("k_shade", {}).get("TCP_TCC_READ_REQ", 0.0)
+            shade_miss = sum(c.get("TCP_TCC_READ_REQ", 0.0) for k, c in pmc.get("counters_per_unit", {}).items() if k != "k_extend")   # k_shade, k_sort_queue, ...
             frame_bound_ms = (l1_miss + shade_miss) * (st["path_bounces"] / steps) / (ceiling * 1e9) * 1e3
             rec["roofline"]["request_rate"] = {
                 "l1_miss_requests_per_unit": l1_miss, "achieved_Greq_per_s": greq, "ceiling_Greq_per_s": ceiling, "frac": greq / ceiling,
-                "whole_frame": {"requests_per_unit_extend_plus_shade": l1_miss + shade_miss, "bound_ms_per_step": frame_bound_ms,
+                "whole_frame": {"requests_per_unit_all_kernels": l1_miss + shade_miss, "bound_ms_per_step": frame_bound_ms,
                                 "measured_ms_per_step": rec["ms_per_step"], "frac": frame_bound_ms / rec["ms_per_step"]},
                 "definition": "TCP_TCC_READ_REQ per path-bounce (PMC pass in profiles/) x units per launch / launch time, against the rate of "
                               "independent random 64- / 128-byte record fetches measured by tools/calib/gather_probe on this chip"}
