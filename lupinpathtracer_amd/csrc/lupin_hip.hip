@@ -283,7 +283,7 @@ static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *sc
     if constexpr (TYPE == LUPIN_PATHTRACE_STANDARD || TYPE == LUPIN_PATHTRACE_MIS) light_stage = use_light_stage(ctx, scene);
     // several material families: sort the queue in windows first, k_shade then finds its 256 paths (nearly) uniform
     SceneDev shade_dev = scene->dev;
-    if (scene->dev.sort_shade && ctx->sort_window)
+    if (scene->dev.sort_shade && ctx->sort_window && scene->dev.num_instances)
     {
         const uint32_t windows = ((blocks / LP_SHARDS) * LP_BLOCK + LP_SORT_WINDOW - 1) / LP_SORT_WINDOW;
         hipLaunchKernelGGL(k_sort_queue<TYPE == LUPIN_PATHTRACE_STANDARD>, dim3(windows * LP_SHARDS), dim3(LP_BLOCK), 0, st, scene->dev, ln->pb, iter);

@@ -1041,28 +1041,37 @@ __global__ void __launch_bounds__(LP_BLOCK) k_sort_queue(SceneDev sc, PathBuffer
     const uint32_t valid = min(LP_SORT_WINDOW, count - base_i);
     if (threadIdx.x < NUM_KEYS) bins[threadIdx.x] = 0u;
     __syncthreads();
+    // Three rounds of independent loads (slots; their hit / meta / RNG words; the hit instances' flags) instead of sixteen
+    // dependent chains: entries past the window's end re-read its last entry and are dropped below.
     uint32_t my_slot[PER_THREAD], my_key[PER_THREAD], my_rank[PER_THREAD];
+    uint32_t hit_w[PER_THREAD], meta_w[PER_THREAD], rng_w[PER_THREAD], flags_w[PER_THREAD];
+    #pragma unroll
+    for (uint32_t r = 0; r < PER_THREAD; r++) my_slot[r] = entries[min(r * LP_BLOCK + threadIdx.x, valid - 1u)];
     #pragma unroll
     for (uint32_t r = 0; r < PER_THREAD; r++)
     {
-        const uint32_t j = r * LP_BLOCK + threadIdx.x;
-        my_key[r] = NUM_KEYS - 1u; my_slot[r] = 0u; my_rank[r] = 0u;
-        if (j < valid)
+        hit_w[r] = __float_as_uint(pb.hit[my_slot[r]].w);
+        meta_w[r] = __float_as_uint(pb.dir_meta[my_slot[r]].w);
+        rng_w[r] = PEEK_COIN ? __float_as_uint(pb.ori_rng[my_slot[r]].w) : 0u;
+    }
+    #pragma unroll
+    for (uint32_t r = 0; r < PER_THREAD; r++) flags_w[r] = sc.instances[hit_w[r] == HIT_MISS ? 0u : hit_w[r]].flags;   // the launch requires an instance
+    #pragma unroll
+    for (uint32_t r = 0; r < PER_THREAD; r++)
+    {
+        my_key[r] = NUM_KEYS - 1u; my_rank[r] = 0u;
+        if (r * LP_BLOCK + threadIdx.x < valid)
         {
-            my_slot[r] = entries[j];
-            const uint32_t inst = __float_as_uint(pb.hit[my_slot[r]].w);
-            const uint32_t meta = __float_as_uint(pb.dir_meta[my_slot[r]].w);
             uint32_t key;
-            if (meta & META_VOLUME) key = 9u;
-            else if (inst == HIT_MISS) key = 8u;
+            if (meta_w[r] & META_VOLUME) key = 9u;
+            else if (hit_w[r] == HIT_MISS) key = 8u;
             else
             {
-                const uint32_t fl = sc.instances[inst].flags;
-                key = (fl >> 8) & 7u;
-                if (fl & (1u << 12)) key |= 16u;
+                key = (flags_w[r] >> 8) & 7u;
+                if (flags_w[r] & (1u << 12)) key |= 16u;
                 else if (PEEK_COIN)
                 {
-                    uint32_t rng = __float_as_uint(pb.ori_rng[my_slot[r]].w);
+                    uint32_t rng = rng_w[r];
                     if (rnd(rng) < 0.5f) key |= 32u;
                 }
             }
