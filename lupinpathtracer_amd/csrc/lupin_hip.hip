@@ -153,10 +153,10 @@ static int ensure_path_buffers(LupinContext *ctx0, Lane *ctx, uint64_t slots, ui
         void **ptrs[] = {(void **)&pb.ori_rng, (void **)&pb.dir_meta, (void **)&pb.weight, (void **)&pb.radiance, (void **)&pb.color,
                          (void **)&pb.hit, (void **)&pb.hit_tri, (void **)&pb.vol0, (void **)&pb.vol1, (void **)&pb.next_hit,
                          (void **)&pb.next_tri, (void **)&pb.queue[0], (void **)&pb.queue[1],
-                         (void **)&pb.sh_org, (void **)&pb.sh_d0, (void **)&pb.sh_f0, (void **)&pb.sh_d1, (void **)&pb.sh_f1, (void **)&pb.sh_hit1};
-        size_t elem[] = {16, 16, 16, 16, 16, 16, 4, 16, 16, 16, 4, 4, 4, 16, 16, 16, 16, 16, 16};
+                         (void **)&pb.sh_org, (void **)&pb.sh_d0, (void **)&pb.sh_f0, (void **)&pb.sh_d1, (void **)&pb.sh_f1, (void **)&pb.sh_hit1, (void **)&pb.skey};
+        size_t elem[] = {16, 16, 16, 16, 16, 16, 4, 16, 16, 16, 4, 4, 4, 16, 16, 16, 16, 16, 16, 4};
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        for (int k = 0; k < 19; k++)
+        for (int k = 0; k < 20; k++)
         {
             if (*ptrs[k]) { hipFree(*ptrs[k]); *ptrs[k] = nullptr; }
             HIP_TRY(hipMalloc(ptrs[k], (size_t)slots * elem[k]));
@@ -286,7 +286,11 @@ static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *sc
     if (scene->dev.sort_shade && ctx->sort_window && scene->dev.num_instances)
     {
         const uint32_t windows = ((blocks / LP_SHARDS) * LP_BLOCK + LP_SORT_WINDOW - 1) / LP_SORT_WINDOW;
-        hipLaunchKernelGGL(k_sort_queue<TYPE == LUPIN_PATHTRACE_STANDARD>, dim3(windows * LP_SHARDS), dim3(LP_BLOCK), 0, st, scene->dev, ln->pb, iter);
+        // the Standard integrator's persistent tracer leaves the key with the hit; otherwise the pass derives it
+        if (TYPE == LUPIN_PATHTRACE_STANDARD && persistent)
+            hipLaunchKernelGGL((k_sort_queue<true, true>), dim3(windows * LP_SHARDS), dim3(LP_BLOCK), 0, st, scene->dev, ln->pb, iter);
+        else
+            hipLaunchKernelGGL((k_sort_queue<TYPE == LUPIN_PATHTRACE_STANDARD, false>), dim3(windows * LP_SHARDS), dim3(LP_BLOCK), 0, st, scene->dev, ln->pb, iter);
         shade_dev.sort_shade = 0;
     }
     if (scene->simple_matte && ctx->specialize_simple)
@@ -522,7 +526,7 @@ void lupin_hip_destroy_context(LupinContext *ctx)
         PathBuffers &pb = ctx->lanes[k].pb;
         void *ptrs[] = {pb.ori_rng, pb.dir_meta, pb.weight, pb.radiance, pb.color, pb.hit, pb.hit_tri, pb.vol0, pb.vol1,
                         pb.next_hit, pb.next_tri, pb.queue[0], pb.queue[1], pb.counts, ctx->lanes[k].stat_counters,
-                        pb.sh_org, pb.sh_d0, pb.sh_f0, pb.sh_d1, pb.sh_f1, pb.sh_hit1, ctx->lanes[k].work_counters};
+                        pb.sh_org, pb.sh_d0, pb.sh_f0, pb.sh_d1, pb.sh_f1, pb.sh_hit1, pb.skey, ctx->lanes[k].work_counters};
         for (void *p : ptrs) if (p) hipFree(p);
         if (ctx->lanes[k].done) hipEventDestroy(ctx->lanes[k].done);
         if (ctx->lanes[k].graph_exec) hipGraphExecDestroy(ctx->lanes[k].graph_exec);

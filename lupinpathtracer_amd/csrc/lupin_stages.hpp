@@ -65,6 +65,7 @@ struct PathBuffers
     // always reads and appends shard b % LP_SHARDS, so a shard never grows beyond its initial size.
     uint32_t *queue[2];   // [parity][shard * shard_cap + i]
     uint32_t *counts;     // counts[k * LP_SHARDS + s] = live paths of shard s entering iteration k
+    uint32_t *skey;       // Standard integrator on the persistent tracer: k_sort_queue's key of the path's hit, written by the tracer
     uint32_t *cursors;    // cursors[(2 k + mode) * LP_SHARDS + s]: how much of shard s the persistent tracer's waves have taken in iteration k
     // Light-pdf stage (k_light_pdf, Standard): k_shade does not append; it tags its queue entry with what became of the
     // path (QUEUE_STATE_*), parks numerator and BSDF pdf of a waiting vertex in sh_f0, and k_light_pdf finishes the
@@ -348,6 +349,22 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launc
 #define LP_REFILL_MIN 16
 #endif
 
+// k_sort_queue's key of a path about to be shaded: what k_shade will execute for it.  Material type of the hit (0..7) | miss (8)
+// | inside a medium (9); +16: the material's smooth hint (delta branch); +32 (Standard integrator only): the outcome of the
+// path's next random number, which for a surface hit outside a medium is the BSDF-or-light-sampling coin
+// (pathtracer.wgsl:640-642) -- the RNG state is read, not advanced.
+constexpr uint32_t LP_SORT_KEYS = 64;
+template <bool PEEK_COIN>
+__device__ __forceinline__ uint32_t shade_sort_key(bool in_medium, bool miss, uint32_t instance_flags, uint32_t rng)
+{
+    if (in_medium) return 9u;
+    if (miss) return 8u;
+    uint32_t key = (instance_flags >> 8) & 7u;
+    if (instance_flags & (1u << 12)) key |= 16u;
+    else if (PEEK_COIN && rnd(rng) < 0.5f) key |= 32u;
+    return key;
+}
+
 // MODE 0: the integrator's closest-hit queries (one per queue entry, stochastic alpha skipping).
 // MODE 1: the shadow rays k_shade recorded for MIS / Direct (two jobs per queue entry, plain closest hit); their hits go
 //         to next_hit / next_tri (MIS ray 0, which doubles as the next vertex) or sh_hit1 / sh_f1.w, and
@@ -385,6 +402,7 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
     // per-lane ray + traversal state
     bool active = false;
     uint32_t slot = 0, rng = 0, rng_in = 0, alpha_k = 0, ray_k = 0;
+    bool in_medium = false;   // META_VOLUME of the path (k_sort_queue's key)
     float total_dst = 0.0f;
     f3 o = splat(0.0f), d = splat(0.0f), inv_d = splat(0.0f);
     f3 co = o, cd = d, cinv = inv_d;
@@ -452,6 +470,7 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
                     o = mk3(orr.x, orr.y, orr.z);
                     d = mk3(dm.x, dm.y, dm.z);
                     rng = rng_in = __float_as_uint(orr.w);
+                    in_medium = (__float_as_uint(dm.w) & META_VOLUME) != 0;
                     total_dst = 0.0f;
                     alpha_k = 0;
                     start_traversal();
@@ -545,10 +564,12 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
             {
                 const bool hit = best.t != LP_F32_MAX;
                 bool again = false;
+                uint32_t inst_flags = 0u;
                 if (hit)
                 {
                     total_dst += best.t;
-                    if (sc.instances[best.inst].flags & 1u)
+                    inst_flags = sc.instances[best.inst].flags;
+                    if (inst_flags & 1u)
                     {
                         Surface sf = resolve_surface(sc, best.inst, best.tri, best.u, best.v);
                         float opacity = surface_opacity(sc, sf);
@@ -569,6 +590,7 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
                     pb.hit[slot] = make_float4(total_dst, best.u, best.v, __uint_as_float(hit ? best.inst : HIT_MISS));
                     pb.hit_tri[slot] = best.tri;
                     if (rng != rng_in) pb.ori_rng[slot].w = __uint_as_float(rng);
+                    if (TYPE == LUPIN_PATHTRACE_STANDARD && sc.sort_shade) pb.skey[slot] = shade_sort_key<true>(in_medium, !hit, inst_flags, rng);
                     active = false;
                 }
             }
@@ -1022,15 +1044,12 @@ __device__ __forceinline__ bool light_pdf_path(const Geo &geo, const SceneDev &s
 #ifndef LP_SORT_WINDOW
 #define LP_SORT_WINDOW 4096
 #endif
-// Key: material type of the hit (0..7) | miss (8) | inside a medium (9), then two more bits where they separate code paths:
-// the material's smooth hint (delta branch), and -- PEEK_COIN, Standard integrator -- the outcome of the path's next random
-// number, which for a surface hit outside a medium is the BSDF-or-light-sampling coin (pathtracer.wgsl:640-642): a wave then
-// runs one of the two samplers instead of both.  The path's RNG state is read, not advanced.
-template <bool PEEK_COIN>
+// The key is shade_sort_key (above); FROM_TRACER: the persistent tracer wrote it when it finished the path's query.
+template <bool PEEK_COIN, bool FROM_TRACER>
 __global__ void __launch_bounds__(LP_BLOCK) k_sort_queue(SceneDev sc, PathBuffers pb, uint32_t iter)
 {
     constexpr uint32_t PER_THREAD = LP_SORT_WINDOW / LP_BLOCK;
-    constexpr uint32_t NUM_KEYS = 64;
+    constexpr uint32_t NUM_KEYS = LP_SORT_KEYS;
     __shared__ uint32_t sorted[LP_SORT_WINDOW];
     __shared__ uint32_t bins[NUM_KEYS];
     const uint32_t shard = blockIdx.x % LP_SHARDS;
@@ -1041,43 +1060,37 @@ __global__ void __launch_bounds__(LP_BLOCK) k_sort_queue(SceneDev sc, PathBuffer
     const uint32_t valid = min(LP_SORT_WINDOW, count - base_i);
     if (threadIdx.x < NUM_KEYS) bins[threadIdx.x] = 0u;
     __syncthreads();
-    // Three rounds of independent loads (slots; their hit / meta / RNG words; the hit instances' flags) instead of sixteen
-    // dependent chains: entries past the window's end re-read its last entry and are dropped below.
+    // Rounds of independent loads instead of sixteen dependent chains: the slots, then either the key the persistent tracer
+    // left for the path (FROM_TRACER: 4 bytes per path) or the path's hit / meta / RNG words and the hit instances' flags.
+    // Entries past the window's end re-read its last entry and are dropped below.
     uint32_t my_slot[PER_THREAD], my_key[PER_THREAD], my_rank[PER_THREAD];
-    uint32_t hit_w[PER_THREAD], meta_w[PER_THREAD], rng_w[PER_THREAD], flags_w[PER_THREAD];
     #pragma unroll
     for (uint32_t r = 0; r < PER_THREAD; r++) my_slot[r] = entries[min(r * LP_BLOCK + threadIdx.x, valid - 1u)];
-    #pragma unroll
-    for (uint32_t r = 0; r < PER_THREAD; r++)
+    if constexpr (FROM_TRACER)
     {
-        hit_w[r] = __float_as_uint(pb.hit[my_slot[r]].w);
-        meta_w[r] = __float_as_uint(pb.dir_meta[my_slot[r]].w);
-        rng_w[r] = PEEK_COIN ? __float_as_uint(pb.ori_rng[my_slot[r]].w) : 0u;
+        #pragma unroll
+        for (uint32_t r = 0; r < PER_THREAD; r++) my_key[r] = pb.skey[my_slot[r]] & (NUM_KEYS - 1u);
+    }
+    else
+    {
+        uint32_t hit_w[PER_THREAD], meta_w[PER_THREAD], rng_w[PER_THREAD], flags_w[PER_THREAD];
+        #pragma unroll
+        for (uint32_t r = 0; r < PER_THREAD; r++)
+        {
+            hit_w[r] = __float_as_uint(pb.hit[my_slot[r]].w);
+            meta_w[r] = __float_as_uint(pb.dir_meta[my_slot[r]].w);
+            rng_w[r] = PEEK_COIN ? __float_as_uint(pb.ori_rng[my_slot[r]].w) : 0u;
+        }
+        #pragma unroll
+        for (uint32_t r = 0; r < PER_THREAD; r++) flags_w[r] = sc.instances[hit_w[r] == HIT_MISS ? 0u : hit_w[r]].flags;   // the launch requires an instance
+        #pragma unroll
+        for (uint32_t r = 0; r < PER_THREAD; r++) my_key[r] = shade_sort_key<PEEK_COIN>((meta_w[r] & META_VOLUME) != 0, hit_w[r] == HIT_MISS, flags_w[r], rng_w[r]);
     }
     #pragma unroll
-    for (uint32_t r = 0; r < PER_THREAD; r++) flags_w[r] = sc.instances[hit_w[r] == HIT_MISS ? 0u : hit_w[r]].flags;   // the launch requires an instance
-    #pragma unroll
     for (uint32_t r = 0; r < PER_THREAD; r++)
     {
-        my_key[r] = NUM_KEYS - 1u; my_rank[r] = 0u;
-        if (r * LP_BLOCK + threadIdx.x < valid)
-        {
-            uint32_t key;
-            if (meta_w[r] & META_VOLUME) key = 9u;
-            else if (hit_w[r] == HIT_MISS) key = 8u;
-            else
-            {
-                key = (flags_w[r] >> 8) & 7u;
-                if (flags_w[r] & (1u << 12)) key |= 16u;
-                else if (PEEK_COIN)
-                {
-                    uint32_t rng = rng_w[r];
-                    if (rnd(rng) < 0.5f) key |= 32u;
-                }
-            }
-            my_key[r] = key;
-            my_rank[r] = atomicAdd(&bins[key], 1u);
-        }
+        my_rank[r] = 0u;
+        if (r * LP_BLOCK + threadIdx.x < valid) my_rank[r] = atomicAdd(&bins[my_key[r]], 1u);
     }
     __syncthreads();
     if (threadIdx.x < 64)   // exclusive prefix of the 64 bins by the first wave
