@@ -336,6 +336,10 @@ def main():
     cam_params = camera_for(api, cam, W, H, keep_aspect)
     res = api.build_pathtrace_resources(ctx, api.BakedPathtraceParams(max_bounces=args.bounces, samples_per_pixel=args.spp))
     out = api.DoubleBufferedTexture(ctx, W, H)
+    # setup, like the two lines above: the path state of all frames in flight (a rank's share of the tiles when sharded)
+    tpx = args.tile_size * 4                                  # LUPIN_WORKGROUP_SIZE pixels per tile_size unit (renderer.rs:807-829)
+    tiles = ((W - 1) // tpx + 1) * ((H - 1) // tpx + 1)
+    ctx.reserve_path_state(W * H if comm is None else -(-tiles // world) * tpx * tpx, args.bounces, args.spp)
     ptype = api.PathtraceType[args.integrator]
     frame = [0]
 

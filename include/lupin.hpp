@@ -101,6 +101,8 @@ class Device   // the reference's (wgpu::Device, wgpu::Queue) pair
     // pathtracer.wgsl:275-289 re-quantises the running mean to f16 every frame (default, LUPIN_ACCUM_F16_RUNNING_AVERAGE);
     // LUPIN_ACCUM_F32 runs the same recurrence on an f32 shadow of each texture and stores the rounded f16 view
     void set_accumulation_mode(int mode) const { check(lupin_hip_set_accumulation_mode(ctx_, mode)); }
+    // path state of every frame in flight allocated now instead of at each lane's first pathtrace call
+    void reserve_path_state(uint64_t pixels, uint32_t max_bounces, uint32_t samples_per_pixel) const { check(lupin_hip_reserve_path_state(ctx_, pixels, max_bounces, samples_per_pixel)); }
   private:
     LupinContext *ctx_ = nullptr;
 };

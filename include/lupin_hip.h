@@ -342,6 +342,12 @@ int lupin_hip_set_f16_store_rounding(LupinContext *ctx, int mode);
  * lupin_hip_texture_download_rgba32f returns the unquantised mean.  The multi-GPU gather moves the f16 view only. */
 enum LupinAccumulationMode { LUPIN_ACCUM_F16_RUNNING_AVERAGE = 0, LUPIN_ACCUM_F32 = 1 };
 int lupin_hip_set_accumulation_mode(LupinContext *ctx, int mode);
+/* Optional: allocate the path state of every frame in flight up front (dispatches of up to `pixels` pixels, baked
+ * max_bounces / samples_per_pixel as in lupin_hip_build_pathtrace_resources).  Without it each of the context's lanes
+ * allocates at its first pathtrace call, i.e. inside the first frames of the host's loop.  No counterpart in the reference
+ * (wgpu allocates its storage buffers in build_pathtrace_resources, renderer.rs:451-640). */
+int lupin_hip_reserve_path_state(LupinContext *ctx, uint64_t pixels, uint32_t max_bounces, uint32_t samples_per_pixel);
+
 
 int lupin_hip_build_pathtrace_resources(LupinContext *ctx, const LupinBakedPathtraceParams *params,
                                         LupinPathtraceResources **out_res);

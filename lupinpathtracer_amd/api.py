@@ -181,6 +181,10 @@ class Context:
             return [conv(x) for x in v] if hasattr(v, "__len__") else v
         return {k: conv(getattr(s, k)) for k, _ in _abi.StatsC._fields_}
 
+    def reserve_path_state(self, pixels, max_bounces, samples_per_pixel):
+        """Allocate the path state of every frame in flight now instead of at each lane's first pathtrace call."""
+        check(lib().lupin_hip_reserve_path_state(self.handle, int(pixels), int(max_bounces), int(samples_per_pixel)))
+
     def set_accumulation_mode(self, mode):
         """0 = f16 running average (reference-faithful, default), 1 = f32 accumulator per texture (pathtracer.wgsl:275-289)."""
         check(lib().lupin_hip_set_accumulation_mode(self.handle, int(mode)))

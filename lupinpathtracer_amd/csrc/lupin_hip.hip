@@ -567,6 +567,22 @@ int lupin_hip_set_accumulation_mode(LupinContext *ctx, int mode)
     return LUPIN_OK;
 }
 
+// Allocates, for every frame in flight, the path state of dispatches up to `pixels` pixels with the given baked parameters --
+// what the first `num_lanes` pathtrace calls would otherwise do one after the other inside the caller's frame loop.
+int lupin_hip_reserve_path_state(LupinContext *ctx, uint64_t pixels, uint32_t max_bounces, uint32_t samples_per_pixel)
+{
+    CTX_ALIVE_TRY(ctx);
+    if (pixels == 0 || pixels > (uint64_t)QUEUE_SLOT_MASK || samples_per_pixel == 0) return fail(LUPIN_ERR_INVALID_ARGUMENT, "bad path-state reservation");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint32_t iterations = samples_per_pixel * (max_bounces + 1);
+    for (int k = 0; k < ctx->num_lanes; k++)
+    {
+        int rc = ensure_path_buffers(ctx, &ctx->lanes[k], pixels, iterations);
+        if (rc != LUPIN_OK) return rc;
+    }
+    return LUPIN_OK;
+}
+
 int lupin_hip_build_pathtrace_resources(LupinContext *ctx, const LupinBakedPathtraceParams *params, LupinPathtraceResources **out_res)
 {
     CTX_ALIVE_TRY(ctx);

@@ -203,3 +203,20 @@ def test_objects_that_outlive_their_context_fail_cleanly(built):
     assert lib.lupin_hip_texture_create(ctx, 8, 8, C.byref(other)) != 0
     lib.lupin_hip_texture_destroy(tex)                                   # frees the device memory, no sync on the dead context
     lib.lupin_hip_dbuf_destroy(dbuf)
+
+
+@pytest.mark.gpu
+def test_reserving_path_state_changes_nothing_but_the_allocation_time(built):
+    """lupin_hip_reserve_path_state allocates every lane's path state up front; frames rendered afterwards equal those of a context
+    that allocates lazily."""
+    from lupinpathtracer_amd import api as lp
+    a, b = lp.Context(0), lp.Context(0)
+    b.reserve_path_state(96 * 64, 8, 2)
+    with pytest.raises(lp.LupinError):
+        b.reserve_path_state(0, 8, 2)
+    outs = []
+    for ctx in (a, b):
+        scene, cams = util.load_scene("arealights1", ctx)
+        outs.append(util.gpu_accumulate(ctx, scene, cams[0], 96, 64, frames=10, spp=2, max_bounces=8))   # more frames than lanes
+    assert util.f16_words_differ(outs[0], outs[1]) == 0
+    a.close(); b.close()
