@@ -39,6 +39,7 @@ struct Lane
 {
     hipStream_t stream = nullptr;
     PathBuffers pb{};
+    char *hot = nullptr;            // the eight per-bounce fields of the path state: capacity x 128 bytes, planes or records (set_path_layout)
     uint64_t capacity = 0;          // slots the path buffers hold
     uint32_t counts_capacity = 0;
     unsigned long long *stat_counters = nullptr;   // per shard: [2s] path bounces, [2s+1] paths
@@ -70,6 +71,7 @@ struct LupinContext
     int last_lane = -1;
     hipEvent_t marker = nullptr;
     bool timing = false;
+    int path_records = -1;          // LUPIN_PATH_RECORDS=0/1: path state as planes / 128-byte records (default: records where the queues are sorted)
     bool sort_window = true;        // LUPIN_SORT_WINDOW=0: k_shade sorts its own 256 paths instead of the k_sort_queue pass
     int light_stage = 0;            // LUPIN_LIGHT_STAGE=1: sample_lights_pdf in its own stage (k_light_pdf) instead of inline in k_shade
     bool debug_sync = false;        // LUPIN_DEBUG_SYNC=1: synchronise and report after every stage launch (fault localisation)
@@ -141,6 +143,26 @@ static hipEvent_t get_event(LupinContext *ctx)
     return e;
 }
 
+// Points the lane's per-bounce fields into its `hot` allocation: planes (neighbouring slots coalesce) or 128-byte records
+// (scattered slots cost two sectors per path, not one per field).  See PathField.
+static void set_path_layout(Lane *ln, bool records)
+{
+    PathBuffers &pb = ln->pb;
+    char *b = ln->hot;
+    const size_t cap = (size_t)ln->capacity;
+    if (records)
+    {
+        const uint32_t st = LP_PATH_RECORD_BYTES;
+        pb.ori_rng = {b + 0, st}; pb.dir_meta = {b + 16, st}; pb.hit = {b + 32, st}; pb.hit_tri = {b + 48, st}; pb.skey = {b + 52, st};
+        pb.weight = {b + 64, st}; pb.radiance = {b + 80, st}; pb.color = {b + 96, st};
+    }
+    else
+    {
+        pb.ori_rng = {b, 16}; pb.dir_meta = {b + 16 * cap, 16}; pb.hit = {b + 32 * cap, 16}; pb.weight = {b + 48 * cap, 16};
+        pb.radiance = {b + 64 * cap, 16}; pb.color = {b + 80 * cap, 16}; pb.hit_tri = {b + 96 * cap, 4}; pb.skey = {b + 100 * cap, 4};
+    }
+}
+
 static int ensure_path_buffers(LupinContext *ctx0, Lane *ctx, uint64_t slots, uint32_t iterations)
 {
     (void)ctx0;
@@ -150,13 +172,12 @@ static int ensure_path_buffers(LupinContext *ctx0, Lane *ctx, uint64_t slots, ui
     if (slots > ctx->capacity)
     {
         PathBuffers &pb = ctx->pb;
-        void **ptrs[] = {(void **)&pb.ori_rng, (void **)&pb.dir_meta, (void **)&pb.weight, (void **)&pb.radiance, (void **)&pb.color,
-                         (void **)&pb.hit, (void **)&pb.hit_tri, (void **)&pb.vol0, (void **)&pb.vol1, (void **)&pb.next_hit,
+        void **ptrs[] = {(void **)&ctx->hot, (void **)&pb.vol0, (void **)&pb.vol1, (void **)&pb.next_hit,
                          (void **)&pb.next_tri, (void **)&pb.queue[0], (void **)&pb.queue[1],
-                         (void **)&pb.sh_org, (void **)&pb.sh_d0, (void **)&pb.sh_f0, (void **)&pb.sh_d1, (void **)&pb.sh_f1, (void **)&pb.sh_hit1, (void **)&pb.skey};
-        size_t elem[] = {16, 16, 16, 16, 16, 16, 4, 16, 16, 16, 4, 4, 4, 16, 16, 16, 16, 16, 16, 4};
+                         (void **)&pb.sh_org, (void **)&pb.sh_d0, (void **)&pb.sh_f0, (void **)&pb.sh_d1, (void **)&pb.sh_f1, (void **)&pb.sh_hit1};
+        size_t elem[] = {LP_PATH_RECORD_BYTES, 16, 16, 16, 4, 4, 4, 16, 16, 16, 16, 16, 16};
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        for (int k = 0; k < 20; k++)
+        for (int k = 0; k < 13; k++)
         {
             if (*ptrs[k]) { hipFree(*ptrs[k]); *ptrs[k] = nullptr; }
             HIP_TRY(hipMalloc(ptrs[k], (size_t)slots * elem[k]));
@@ -490,6 +511,7 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
     ctx->debug_sync = dbs && strcmp(dbs, "0") != 0;
     if (const char *lsg = getenv("LUPIN_LIGHT_STAGE")) ctx->light_stage = atoi(lsg) != 0 ? 1 : 0;
     if (const char *sw = getenv("LUPIN_SORT_WINDOW")) ctx->sort_window = atoi(sw) != 0;
+    if (const char *pr = getenv("LUPIN_PATH_RECORDS")) ctx->path_records = atoi(pr) != 0 ? 1 : 0;
     const char *ssh = getenv("LUPIN_SIMPLE_SHADE");
     if (ssh && strcmp(ssh, "0") == 0) ctx->specialize_simple = false;
     const char *gr = getenv("LUPIN_GRAPH");
@@ -524,9 +546,9 @@ void lupin_hip_destroy_context(LupinContext *ctx)
     for (int k = 0; k < LP_MAX_LANES; k++)
     {
         PathBuffers &pb = ctx->lanes[k].pb;
-        void *ptrs[] = {pb.ori_rng, pb.dir_meta, pb.weight, pb.radiance, pb.color, pb.hit, pb.hit_tri, pb.vol0, pb.vol1,
+        void *ptrs[] = {ctx->lanes[k].hot, pb.vol0, pb.vol1,
                         pb.next_hit, pb.next_tri, pb.queue[0], pb.queue[1], pb.counts, ctx->lanes[k].stat_counters,
-                        pb.sh_org, pb.sh_d0, pb.sh_f0, pb.sh_d1, pb.sh_f1, pb.sh_hit1, pb.skey, ctx->lanes[k].work_counters};
+                        pb.sh_org, pb.sh_d0, pb.sh_f0, pb.sh_d1, pb.sh_f1, pb.sh_hit1, ctx->lanes[k].work_counters};
         for (void *p : ptrs) if (p) hipFree(p);
         if (ctx->lanes[k].done) hipEventDestroy(ctx->lanes[k].done);
         if (ctx->lanes[k].graph_exec) hipGraphExecDestroy(ctx->lanes[k].graph_exec);
@@ -1252,6 +1274,8 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
     const uint32_t iterations = fp.spp * (fp.max_bounces + 1);
     int rc = ensure_path_buffers(ctx, ln, n, iterations);
     if (rc != LUPIN_OK) return rc;
+    // scenes whose queues get sorted by material read the path state at scattered slots: records; otherwise planes
+    set_path_layout(ln, ctx->path_records < 0 ? (scene->dev.sort_shade && ctx->sort_window) : ctx->path_records != 0);
 
     // grid: every shard gets the same number of blocks, block b serves shard b % LP_SHARDS
     const uint32_t blocks_needed = (n + LP_BLOCK - 1) / LP_BLOCK;

@@ -39,15 +39,29 @@ constexpr uint32_t META_TERMINATED = 1u << 14;     // MIS / Direct: the path end
 constexpr uint32_t META_SAMPLE_SHIFT = 16;
 constexpr uint32_t HIT_MISS = 0xFFFFFFFFu;
 
+// A per-path field of the path state, `field[slot]`.  The eight fields every bounce touches live in one allocation that is
+// laid out either as planes (stride = the element: neighbouring slots coalesce -- scenes whose queues stay in pixel order)
+// or as one 128-byte record per path (stride 128: a path's fields share two 64-byte sectors -- scenes whose queues are
+// sorted by material, where the slots of a wave are scattered and a plane costs one request per field and lane):
+//   sector 0: ori_rng 0, dir_meta 16, hit 32, hit_tri 48, skey 52      sector 1: weight 64, radiance 80, color 96
+template <typename T>
+struct PathField
+{
+    char *base;
+    uint32_t stride;
+    __device__ __forceinline__ T &operator[](size_t slot) const { return *reinterpret_cast<T *>(base + slot * stride); }
+};
+constexpr uint32_t LP_PATH_RECORD_BYTES = 128;
+
 struct PathBuffers
 {
-    float4 *ori_rng;    // ori.xyz | rng state
-    float4 *dir_meta;   // dir.xyz | meta
-    float4 *weight;     // weight.xyz
-    float4 *radiance;   // radiance.xyz
-    float4 *color;      // per-pixel sum over samples
-    float4 *hit;        // dst u v | instance (HIT_MISS = no hit)
-    uint32_t *hit_tri;  // global triangle
+    PathField<float4> ori_rng;    // ori.xyz | rng state
+    PathField<float4> dir_meta;   // dir.xyz | meta
+    PathField<float4> weight;     // weight.xyz
+    PathField<float4> radiance;   // radiance.xyz
+    PathField<float4> color;      // per-pixel sum over samples
+    PathField<float4> hit;        // dst u v | instance (HIT_MISS = no hit)
+    PathField<uint32_t> hit_tri;  // global triangle
     float4 *vol0;       // medium density.xyz | anisotropy
     float4 *vol1;       // medium scattering.xyz
     float4 *next_hit;   // MIS: hit of the BSDF-sampled shadow ray, reused as next vertex
@@ -65,7 +79,7 @@ struct PathBuffers
     // always reads and appends shard b % LP_SHARDS, so a shard never grows beyond its initial size.
     uint32_t *queue[2];   // [parity][shard * shard_cap + i]
     uint32_t *counts;     // counts[k * LP_SHARDS + s] = live paths of shard s entering iteration k
-    uint32_t *skey;       // Standard integrator on the persistent tracer: k_sort_queue's key of the path's hit, written by the tracer
+    PathField<uint32_t> skey;     // Standard integrator on the persistent tracer: k_sort_queue's key of the path's hit, written by the tracer
     uint32_t *cursors;    // cursors[(2 k + mode) * LP_SHARDS + s]: how much of shard s the persistent tracer's waves have taken in iteration k
     // Light-pdf stage (k_light_pdf, Standard): k_shade does not append; it tags its queue entry with what became of the
     // path (QUEUE_STATE_*), parks numerator and BSDF pdf of a waiting vertex in sh_f0, and k_light_pdf finishes the
