@@ -64,15 +64,17 @@ struct PathBuffers
     PathField<uint32_t> hit_tri;  // global triangle
     float4 *vol0;       // medium density.xyz | anisotropy
     float4 *vol1;       // medium scattering.xyz
-    float4 *next_hit;   // MIS: hit of the BSDF-sampled shadow ray, reused as next vertex
-    uint32_t *next_tri;
+    // The MIS / Direct fields share a second allocation with the same two layouts; as records:
+    //   sector 0: sh_org 0, sh_d0 16, sh_d1 32, next_tri 48      sector 1: sh_f0 64, sh_f1 80, next_hit 96, sh_hit1 112
+    PathField<float4> next_hit;   // MIS: hit of the BSDF-sampled shadow ray, reused as next vertex
+    PathField<uint32_t> next_tri;
     // MIS / Direct shadow rays, recorded by k_shade and traced by k_shadow (radiance += factor * emission (*|/) scalar)
-    float4 *sh_org;     // origin.xyz | flags (bit0: ray 0 valid, bit1: ray 1 valid)
-    float4 *sh_d0;      // ray 0 direction | scalar 0
-    float4 *sh_f0;      // ray 0 factor = weight * bsdfcos
-    float4 *sh_d1;      // ray 1 direction | scalar 1
-    float4 *sh_f1;      // ray 1 factor (.w: triangle of the pre-traced hit, see sh_hit1)
-    float4 *sh_hit1;    // large scenes trace the shadow rays in the persistent kernel: hit record of ray 1 (ray 0 -> next_hit)
+    PathField<float4> sh_org;     // origin.xyz | flags (bit0: ray 0 valid, bit1: ray 1 valid)
+    PathField<float4> sh_d0;      // ray 0 direction | scalar 0
+    PathField<float4> sh_f0;      // ray 0 factor = weight * bsdfcos
+    PathField<float4> sh_d1;      // ray 1 direction | scalar 1
+    PathField<float4> sh_f1;      // ray 1 factor (.w: triangle of the pre-traced hit, see sh_hit1)
+    PathField<float4> sh_hit1;    // large scenes trace the shadow rays in the persistent kernel: hit record of ray 1 (ray 0 -> next_hit)
     // Live-path queues, sharded: one global counter per iteration would serialise every wave's append on a
     // single L2 atomic (~88 per microsecond chip-wide -- measured: 186 us per 1M-path iteration, more than the
     // shading itself).  Each of LP_SHARDS shards owns a fixed segment of the queue and its own counter; block b
@@ -1271,7 +1273,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LP_LIGHT_PDF_MIS_WAVES, 8))) 
         const uint32_t it = items[j], t = it >> 1, k = it & 1u;
         const uint32_t s = entry_slot[t];
         const float4 so = pb.sh_org[s];
-        float4 *rec = (k ? pb.sh_d1 : pb.sh_d0) + s;
+        float4 *rec = &(k ? pb.sh_d1 : pb.sh_d0)[s];
         const float4 dd = *rec;
         const float light_pdf = lights_pdf(geo, sc, lds_stack, mk3(so.x, so.y, so.z), mk3(dd.x, dd.y, dd.z), fp.pc.ray_epsilon);
         const float b_pdf = dd.w;
