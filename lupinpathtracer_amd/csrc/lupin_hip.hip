@@ -41,6 +41,7 @@ struct Lane
     PathBuffers pb{};
     char *hot = nullptr;            // the eight per-bounce fields of the path state: capacity x 128 bytes, planes or records (set_path_layout)
     char *shadow = nullptr;         // the eight MIS / Direct fields, likewise
+    char *skey = nullptr;           // k_sort_queue's keys, 4 bytes per slot
     uint64_t capacity = 0;          // slots the path buffers hold
     uint32_t counts_capacity = 0;
     unsigned long long *stat_counters = nullptr;   // per shard: [2s] path bounces, [2s+1] paths
@@ -151,10 +152,11 @@ static void set_path_layout(Lane *ln, bool records)
     PathBuffers &pb = ln->pb;
     char *b = ln->hot;
     const size_t cap = (size_t)ln->capacity;
+    pb.skey = {ln->skey, 4};   // always a plane: k_sort_queue reads nothing else of a path
     if (records)
     {
         const uint32_t st = LP_PATH_RECORD_BYTES;
-        pb.ori_rng = {b + 0, st}; pb.dir_meta = {b + 16, st}; pb.hit = {b + 32, st}; pb.hit_tri = {b + 48, st}; pb.skey = {b + 52, st};
+        pb.ori_rng = {b + 0, st}; pb.dir_meta = {b + 16, st}; pb.hit = {b + 32, st}; pb.hit_tri = {b + 48, st};
         pb.weight = {b + 64, st}; pb.radiance = {b + 80, st}; pb.color = {b + 96, st};
         char *m = ln->shadow;
         pb.sh_org = {m + 0, st}; pb.sh_d0 = {m + 16, st}; pb.sh_d1 = {m + 32, st}; pb.next_tri = {m + 48, st};
@@ -163,7 +165,7 @@ static void set_path_layout(Lane *ln, bool records)
     else
     {
         pb.ori_rng = {b, 16}; pb.dir_meta = {b + 16 * cap, 16}; pb.hit = {b + 32 * cap, 16}; pb.weight = {b + 48 * cap, 16};
-        pb.radiance = {b + 64 * cap, 16}; pb.color = {b + 80 * cap, 16}; pb.hit_tri = {b + 96 * cap, 4}; pb.skey = {b + 100 * cap, 4};
+        pb.radiance = {b + 64 * cap, 16}; pb.color = {b + 80 * cap, 16}; pb.hit_tri = {b + 96 * cap, 4};
         char *m = ln->shadow;
         pb.sh_org = {m, 16}; pb.sh_d0 = {m + 16 * cap, 16}; pb.sh_d1 = {m + 32 * cap, 16}; pb.sh_f0 = {m + 48 * cap, 16};
         pb.sh_f1 = {m + 64 * cap, 16}; pb.next_hit = {m + 80 * cap, 16}; pb.sh_hit1 = {m + 96 * cap, 16}; pb.next_tri = {m + 112 * cap, 4};
@@ -179,10 +181,10 @@ static int ensure_path_buffers(LupinContext *ctx0, Lane *ctx, uint64_t slots, ui
     if (slots > ctx->capacity)
     {
         PathBuffers &pb = ctx->pb;
-        void **ptrs[] = {(void **)&ctx->hot, (void **)&ctx->shadow, (void **)&pb.vol0, (void **)&pb.vol1, (void **)&pb.queue[0], (void **)&pb.queue[1]};
-        size_t elem[] = {LP_PATH_RECORD_BYTES, LP_PATH_RECORD_BYTES, 16, 16, 4, 4};
+        void **ptrs[] = {(void **)&ctx->hot, (void **)&ctx->shadow, (void **)&ctx->skey, (void **)&pb.vol0, (void **)&pb.vol1, (void **)&pb.queue[0], (void **)&pb.queue[1]};
+        size_t elem[] = {LP_PATH_RECORD_BYTES, LP_PATH_RECORD_BYTES, 4, 16, 16, 4, 4};
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        for (int k = 0; k < 6; k++)
+        for (int k = 0; k < 7; k++)
         {
             if (*ptrs[k]) { hipFree(*ptrs[k]); *ptrs[k] = nullptr; }
             HIP_TRY(hipMalloc(ptrs[k], (size_t)slots * elem[k]));
@@ -551,7 +553,7 @@ void lupin_hip_destroy_context(LupinContext *ctx)
     for (int k = 0; k < LP_MAX_LANES; k++)
     {
         PathBuffers &pb = ctx->lanes[k].pb;
-        void *ptrs[] = {ctx->lanes[k].hot, ctx->lanes[k].shadow, pb.vol0, pb.vol1, pb.queue[0], pb.queue[1], pb.counts, ctx->lanes[k].stat_counters,
+        void *ptrs[] = {ctx->lanes[k].hot, ctx->lanes[k].shadow, ctx->lanes[k].skey, pb.vol0, pb.vol1, pb.queue[0], pb.queue[1], pb.counts, ctx->lanes[k].stat_counters,
                         ctx->lanes[k].work_counters};
         for (void *p : ptrs) if (p) hipFree(p);
         if (ctx->lanes[k].done) hipEventDestroy(ctx->lanes[k].done);

@@ -43,7 +43,7 @@ constexpr uint32_t HIT_MISS = 0xFFFFFFFFu;
 // laid out either as planes (stride = the element: neighbouring slots coalesce -- scenes whose queues stay in pixel order)
 // or as one 128-byte record per path (stride 128: a path's fields share two 64-byte sectors -- scenes whose queues are
 // sorted by material, where the slots of a wave are scattered and a plane costs one request per field and lane):
-//   sector 0: ori_rng 0, dir_meta 16, hit 32, hit_tri 48, skey 52      sector 1: weight 64, radiance 80, color 96
+//   sector 0: ori_rng 0, dir_meta 16, hit 32, hit_tri 48      sector 1: weight 64, radiance 80, color 96
 template <typename T>
 struct PathField
 {
@@ -81,7 +81,7 @@ struct PathBuffers
     // always reads and appends shard b % LP_SHARDS, so a shard never grows beyond its initial size.
     uint32_t *queue[2];   // [parity][shard * shard_cap + i]
     uint32_t *counts;     // counts[k * LP_SHARDS + s] = live paths of shard s entering iteration k
-    PathField<uint32_t> skey;     // Standard integrator on the persistent tracer: k_sort_queue's key of the path's hit, written by the tracer
+    PathField<uint32_t> skey;     // Standard integrator on the persistent tracer: k_sort_queue's key of the path's hit, written by the tracer (always a plane)
     uint32_t *cursors;    // cursors[(2 k + mode) * LP_SHARDS + s]: how much of shard s the persistent tracer's waves have taken in iteration k
     // Light-pdf stage (k_light_pdf, Standard): k_shade does not append; it tags its queue entry with what became of the
     // path (QUEUE_STATE_*), parks numerator and BSDF pdf of a waiting vertex in sh_f0, and k_light_pdf finishes the
