@@ -383,6 +383,8 @@ class Comm
         return out;
     }
     void gather_framebuffer(TextureRef tex, uint32_t tile_size) const { check(lupin_hip_gather_framebuffer(c_, tex.raw(), tile_size)); }
+    // readback form: only `root` receives the other ranks' tiles
+    void gather_framebuffer_to(TextureRef tex, uint32_t tile_size, uint32_t root) const { check(lupin_hip_gather_framebuffer_to(c_, tex.raw(), tile_size, root)); }
     void barrier() const { check(lupin_hip_comm_barrier(c_)); }
     uint32_t rank() const { return lupin_hip_comm_rank(c_); }
     uint32_t world() const { return lupin_hip_comm_world(c_); }

@@ -525,7 +525,8 @@ int lupin_hip_unpack_gathered_tiles(LupinContext *ctx, LupinTexture *tex, uint32
  * No counterpart in the reference (single device; its TileParams sub-dispatch, renderer.rs:807-829, is what the shards
  * are made of).  A host renders its tiles with lupin_hip_pathtrace_scene_tiles for any number of accumulation frames
  * (no communication) and calls lupin_hip_gather_framebuffer once per readback: every rank then holds the whole frame,
- * bit-identical to the single-GPU render.  librccl is dlopen'ed on first use (LUPIN_RCCL_LIB overrides the name).
+ * bit-identical to the single-GPU render.  librccl is dlopen'ed on first use (LUPIN_RCCL_LIB names the one library to load instead of the default sonames;
+ * a library that cannot be loaded makes every communicator call return LUPIN_ERR_RCCL).
  *
  * One process per GPU:  rank 0 calls lupin_hip_comm_get_unique_id and hands the 128 bytes to the other ranks by any
  *                       means (file, socket, MPI); every rank then calls lupin_hip_comm_init_rank.
@@ -545,6 +546,10 @@ uint32_t lupin_hip_comm_world(const LupinComm *comm);
  * stream after every frame enqueued so far (asynchronous like pathtrace_scene; download / lupin_hip_sync waits). */
 int lupin_hip_gather_framebuffer(LupinComm *comm, LupinTexture *tex, uint32_t tile_size);
 int lupin_hip_gather_framebuffer_all(LupinComm *const *comms, LupinTexture *const *texs, uint32_t n, uint32_t tile_size);
+/* the readback form: only `root` receives (one grouped ncclSend per peer / ncclRecv per peer on the root, exact payload
+ * sizes), so a 3840 x 2160 readback moves 66 MB once instead of to every rank; the other ranks' textures keep their own
+ * tiles only.  Same enqueue semantics as lupin_hip_gather_framebuffer. */
+int lupin_hip_gather_framebuffer_to(LupinComm *comm, LupinTexture *tex, uint32_t tile_size, uint32_t root);
 /* host-side reductions over the ranks for measurement loops (op 0 = sum, 1 = max); synchronous, and every frame this
  * rank enqueued has completed when they return, so lupin_hip_comm_barrier brackets a timed region */
 int lupin_hip_comm_allreduce_f64(LupinComm *comm, double *inout, uint32_t n, uint32_t op);

@@ -101,6 +101,7 @@ extern "C" {
     pub fn lupin_hip_comm_world(comm: *const LupinComm) -> u32;
     pub fn lupin_hip_gather_framebuffer(comm: *mut LupinComm, tex: *mut LupinTexture, tile_size: u32) -> c_int;
     pub fn lupin_hip_gather_framebuffer_all(comms: *const *mut LupinComm, texs: *const *mut LupinTexture, n: u32, tile_size: u32) -> c_int;
+    pub fn lupin_hip_gather_framebuffer_to(comm: *mut LupinComm, tex: *mut LupinTexture, tile_size: u32, root: u32) -> c_int;
     pub fn lupin_hip_comm_barrier(comm: *mut LupinComm) -> c_int;
     pub fn lupin_hip_comm_allreduce_f64(comm: *mut LupinComm, inout: *mut f64, n: u32, op: u32) -> c_int;
     // accumulation mode (f16 running average = reference, or f32 accumulator) and its readback

@@ -204,6 +204,7 @@ SYMBOLS = [
     ("lupin_hip_comm_world", _U32, [_P]),
     ("lupin_hip_gather_framebuffer", C.c_int, [_P, _P, _U32]),
     ("lupin_hip_gather_framebuffer_all", C.c_int, [_PP, _PP, _U32, _U32]),
+    ("lupin_hip_gather_framebuffer_to", C.c_int, [_P, _P, _U32, _U32]),
     ("lupin_hip_comm_allreduce_f64", C.c_int, [_P, _P, _U32, _U32]),
     ("lupin_hip_comm_barrier", C.c_int, [_P]),
     ("lupin_build_bvh", C.c_int64, [_P, _U32, _P, _U32, _P, C.c_uint64]),

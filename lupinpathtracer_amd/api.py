@@ -837,6 +837,10 @@ class Comm:
         """pack own tiles -> all-gather -> scatter the others' tiles; enqueued, `texture.download()` / `ctx.sync()` waits."""
         check(lib().lupin_hip_gather_framebuffer(self.handle, texture.handle, tile_size))
 
+    def gather_framebuffer_to(self, texture, tile_size, root=0):
+        """pack own tiles -> grouped ncclSend / ncclRecv -> the root scatters: only `root` ends up with the whole frame."""
+        check(lib().lupin_hip_gather_framebuffer_to(self.handle, texture.handle, tile_size, root))
+
     def allreduce(self, values, op="sum"):
         a = np.ascontiguousarray(values, dtype=np.float64).copy()
         check(lib().lupin_hip_comm_allreduce_f64(self.handle, ptr(a), a.size, {"sum": 0, "max": 1}[op]))

@@ -28,6 +28,8 @@ struct Rccl
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -38,14 +40,24 @@ Rccl *rccl()
 {
     static Rccl r;
     if (r.handle || !r.error.empty()) return &r;
-    const char *names[] = {getenv("LUPIN_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char *n : names)
-    {
-        if (!n || !*n) continue;
+    // LUPIN_RCCL_LIB names THE library to use (no fallback: a host that points at a build wants that build or an error);
+    // without it the usual sonames are tried in order.
+    const char *forced = getenv("LUPIN_RCCL_LIB");
+    const char *defaults[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    std::string why;
+    auto try_load = [&](const char *n) {
         r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-        if (r.handle) break;
-    }
-    if (!r.handle) { r.error = std::string("librccl could not be loaded: ") + (dlerror() ? dlerror() : "?"); return &r; }
+        if (!r.handle)
+        {
+            const char *e = dlerror();   // one call: dlerror() clears the message it returns
+            if (!why.empty()) why += "; ";
+            why += e ? e : (std::string(n) + ": unknown dlopen error");
+        }
+        return r.handle != nullptr;
+    };
+    if (forced && *forced) try_load(forced);
+    else for (const char *n : defaults) if (try_load(n)) break;
+    if (!r.handle) { r.error = "librccl could not be loaded: " + why; return &r; }
     bool ok = true;
     auto sym = [&](const char *n) { void *p = dlsym(r.handle, n); if (!p) { ok = false; r.error = std::string("librccl lacks ") + n; } return p; };
     r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
@@ -54,6 +66,8 @@ Rccl *rccl()
     r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
     r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
     r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
+    r.Send = (decltype(r.Send))sym("ncclSend");
+    r.Recv = (decltype(r.Recv))sym("ncclRecv");
     r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
     r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
     r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
@@ -234,6 +248,46 @@ int lupin_hip_gather_framebuffer(LupinComm *c, LupinTexture *tex, uint32_t tile_
     Rccl *R; int rc = need_rccl(&R); if (rc) return rc;
     for (int stage = 0; stage < 3; stage++)
         if ((rc = gather_enqueue(R, c, tex, tile_size, stage))) return rc;
+    return LUPIN_OK;
+}
+
+// Readback gather: only `root` receives.  Every other rank packs its tiles and sends the exact payload; the root posts one
+// receive per peer into that peer's slice of the staging buffer (the all-gather's layout) and scatters them with the same
+// one-launch unpack.  One RCCL group per call, so the sends and receives of a rank cannot order-deadlock.  Ranks other than
+// the root keep a framebuffer that holds their own tiles only.
+int lupin_hip_gather_framebuffer_to(LupinComm *c, LupinTexture *tex, uint32_t tile_size, uint32_t root)
+{
+    if (!c || !tex || tile_size == 0 || root >= c->world) return COMM_FAIL(LUPIN_ERR_INVALID_ARGUMENT, "bad gather arguments");
+    if (!lupin_internal_ctx_alive(c->ctx)) return COMM_FAIL(LUPIN_ERR_INVALID_ARGUMENT, "the context of this object has been destroyed");
+    Rccl *R; int rc = need_rccl(&R); if (rc) return rc;
+    if ((rc = gather_enqueue(R, c, tex, tile_size, 0))) return rc;   // staging + pack of the own tiles
+    if (c->world == 1) return LUPIN_OK;
+    LupinContext *ctx = c->ctx;
+    hipStream_t st = lupin_internal_ctx_stream(ctx);
+    HIP_TRY_C(hipSetDevice(lupin_internal_ctx_device(ctx)));
+    NCCL_TRY(R->GroupStart());
+    if (c->rank == root)
+    {
+        for (uint32_t r = 0; r < c->world; r++)
+        {
+            if (r == root) continue;
+            const uint64_t px = lupin_hip_packed_tile_pixels(tex->width, tex->height, tile_size, r, c->world);
+            if (px == 0) continue;
+            ncclResult_t e = R->Recv(c->recv + (size_t)r * c->capacity_px, (size_t)px * 8, ncclUint8, (int)r, c->comm, st);
+            if (e != ncclSuccess) { R->GroupEnd(); return COMM_FAIL(LUPIN_ERR_RCCL, R->GetErrorString ? R->GetErrorString(e) : "ncclRecv"); }
+        }
+    }
+    else
+    {
+        const uint64_t px = lupin_hip_packed_tile_pixels(tex->width, tex->height, tile_size, c->rank, c->world);
+        if (px)
+        {
+            ncclResult_t e = R->Send(c->send, (size_t)px * 8, ncclUint8, (int)root, c->comm, st);
+            if (e != ncclSuccess) { R->GroupEnd(); return COMM_FAIL(LUPIN_ERR_RCCL, R->GetErrorString ? R->GetErrorString(e) : "ncclSend"); }
+        }
+    }
+    NCCL_TRY(R->GroupEnd());
+    if (c->rank == root) return gather_enqueue(R, c, tex, tile_size, 2);
     return LUPIN_OK;
 }
 

@@ -184,19 +184,23 @@ static int ensure_path_buffers(LupinContext *ctx0, Lane *ctx, uint64_t slots, ui
         void **ptrs[] = {(void **)&ctx->hot, (void **)&ctx->shadow, (void **)&ctx->skey, (void **)&pb.vol0, (void **)&pb.vol1, (void **)&pb.queue[0], (void **)&pb.queue[1]};
         size_t elem[] = {LP_PATH_RECORD_BYTES, LP_PATH_RECORD_BYTES, 4, 16, 16, 4, 4};
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        for (int k = 0; k < 7; k++)
-        {
-            if (*ptrs[k]) { hipFree(*ptrs[k]); *ptrs[k] = nullptr; }
-            HIP_TRY(hipMalloc(ptrs[k], (size_t)slots * elem[k]));
-        }
-        ctx->capacity = slots;
+        // the lane holds nothing until every allocation has succeeded: a failure part-way (hipMalloc returns through
+        // HIP_TRY) must not leave a capacity behind that a later, smaller dispatch would trust
+        ctx->capacity = 0;
         ctx->pb_generation++;
+        for (int k = 0; k < 7; k++)
+            if (*ptrs[k]) { hipFree(*ptrs[k]); *ptrs[k] = nullptr; }
+        for (int k = 0; k < 7; k++)
+            HIP_TRY(hipMalloc(ptrs[k], (size_t)slots * elem[k]));
+        ctx->capacity = slots;
     }
     if (iterations + 2 > ctx->counts_capacity)
     {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->counts_capacity = 0;
         if (ctx->pb.counts) hipFree(ctx->pb.counts);
         ctx->pb.counts = nullptr;
+        ctx->pb.cursors = nullptr;
         // queue counters, then the persistent tracer's hand-out cursors (two per iteration): one allocation, one clear per call
         HIP_TRY(hipMalloc((void **)&ctx->pb.counts, 3 * (size_t)(iterations + 2) * LP_SHARDS * sizeof(uint32_t)));
         ctx->counts_capacity = iterations + 2;
@@ -442,8 +446,11 @@ int lupin_internal_tiles_copy(LupinContext *ctx, const LupinTexture *tex, void *
     const uint32_t ntx = (tex->width - 1) / tpx + 1, nty = (tex->height - 1) / tpx + 1;
     const uint32_t blocks = mode == 2 ? ntx * nty : lupin_owned_tile_count(ntx * nty, rank, world);
     join_primary(ctx);
+    // unpacked texels also refresh a valid f32 accumulator (widened: another rank's tile arrives as f16), so that
+    // lupin_hip_texture_download_rgba32f and the next frame's blend see the gathered frame, not stale or zero words
+    float4 *shadow = (mode != 0 && tex->accum32 && tex->accum32_valid) ? tex->accum32 : nullptr;
     if (blocks)
-        hipLaunchKernelGGL(k_tiles_copy, dim3(blocks), dim3(LP_BLOCK), 0, ctx->stream, (uint2 *)tex->data, (uint2 *)packed, tex->width, tex->height,
+        hipLaunchKernelGGL(k_tiles_copy, dim3(blocks), dim3(LP_BLOCK), 0, ctx->stream, (uint2 *)tex->data, (uint2 *)packed, shadow, tex->width, tex->height,
                            tpx, rank, world, (unsigned long long)capacity_px, mode);
     HIP_TRY(hipGetLastError());
     return LUPIN_OK;
@@ -500,7 +507,11 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
         if (e == hipSuccess) e = hipMemsetAsync(ln.work_counters, 0, LP_WORK_WORDS * sizeof(unsigned long long), ln.stream);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->marker, hipEventDisableTiming);
-    if (e != hipSuccess) { delete ctx; return fail(LUPIN_ERR_HIP, std::string("context setup: ") + hipGetErrorString(e)); }
+    if (e != hipSuccess)
+    {
+        lupin_hip_destroy_context(ctx);   // one cleanup path: registry entry, streams, events and buffers of the lanes made so far
+        return fail(LUPIN_ERR_HIP, std::string("context setup: ") + hipGetErrorString(e));
+    }
     ctx->stream = ctx->lanes[0].stream;
     const char *ext = getenv("LUPIN_EXTEND");
     if (ext && strcmp(ext, "persistent") == 0) ctx->persistent_extend = 1;
@@ -527,7 +538,7 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
     {
         // Graph replay is validated on the runtime this library was built against (HIP_VERSION major.minor).  Round 1 saw a
         // memory fault on replay when a PyTorch wheel's older libamdhip64 served the process: refuse rather than risk it.
-        delete ctx;
+        lupin_hip_destroy_context(ctx);
         return fail(LUPIN_ERR_HIP, "LUPIN_GRAPH=1 needs the HIP runtime this library was built against (built " + std::to_string(HIP_VERSION) +
                                    ", running on " + std::to_string(ri.runtime_hip_version) + ")");
     }

@@ -1746,7 +1746,8 @@ __global__ void __launch_bounds__(LP_BLOCK) k_detmath(int fn, uint32_t n, const 
 //   mode 1: unpack the tiles `rank` owns from packed[0 ..)
 //   mode 2: unpack every tile NOT owned by `rank` (blockIdx.x = tile of the frame) from the all-gathered buffer
 //           packed[owner * capacity_px + ..) -- the whole readback scatter in one launch
-__global__ void __launch_bounds__(LP_BLOCK) k_tiles_copy(uint2 *tex, uint2 *packed, uint32_t width, uint32_t height, uint32_t tile_px,
+// The unpack modes also write the widened texel into `accum32` when the texture carries a valid f32 accumulator.
+__global__ void __launch_bounds__(LP_BLOCK) k_tiles_copy(uint2 *tex, uint2 *packed, float4 *accum32, uint32_t width, uint32_t height, uint32_t tile_px,
                                                         uint32_t rank, uint32_t world, unsigned long long capacity_px, int mode)
 {
     const uint32_t ntx = (width - 1) / tile_px + 1;
@@ -1781,7 +1782,14 @@ __global__ void __launch_bounds__(LP_BLOCK) k_tiles_copy(uint2 *tex, uint2 *pack
     {
         const uint32_t x = ox + p % w, y = oy + p / w;
         if (mode == 0) packed[before + p] = tex[(size_t)y * width + x];
-        else tex[(size_t)y * width + x] = packed[before + p];
+        else
+        {
+            const uint2 w = packed[before + p];
+            tex[(size_t)y * width + x] = w;
+            if (accum32)   // the texture's f32 accumulator follows (LUPIN_ACCUM_F32): the unpacked texel widened
+                accum32[(size_t)y * width + x] = make_float4(half_bits_to_float(w.x & 0xFFFFu), half_bits_to_float(w.x >> 16),
+                                                             half_bits_to_float(w.y & 0xFFFFu), half_bits_to_float(w.y >> 16));
+        }
     }
 }
 

@@ -94,30 +94,61 @@ def rendezvous_path(env=None):
     return os.path.join(env.get("TMPDIR", "/tmp"), f"lupin_rdzv_{os.getppid()}_{env.get('MASTER_PORT', '0')}")
 
 
+def job_nonce(env=None):
+    """32 bytes naming THIS job: the launcher's pid, its start time (so a recycled pid is another job) and MASTER_PORT.
+    Every rank of one launch computes the same value; a file left behind by a job that died carries another one."""
+    import hashlib
+    env = os.environ if env is None else env
+    ppid = os.getppid()
+    start = "?"
+    try:
+        with open(f"/proc/{ppid}/stat") as f:
+            start = f.read().rsplit(")", 1)[1].split()[19]   # field 22: starttime in clock ticks since boot
+    except (OSError, IndexError):
+        pass
+    return hashlib.sha256(f"{ppid}:{start}:{env.get('MASTER_PORT', '0')}:{env.get('LUPIN_RDZV_NONCE', '')}".encode()).digest()
+
+
+def publish_unique_id(path, uid, nonce):
+    """Rank 0: remove whatever is at `path` (a leftover of a dead job), then publish id + nonce atomically."""
+    try:
+        os.remove(path)
+    except OSError:
+        pass
+    tmp = f"{path}.{os.getpid()}.tmp"
+    with open(tmp, "wb") as f:
+        f.write(uid + nonce)
+    os.replace(tmp, path)
+
+
+def wait_unique_id(path, nonce, timeout=300.0, rank=-1):
+    """Other ranks: wait for a file that carries THIS job's nonce; anything else at the path is ignored."""
+    deadline = time.monotonic() + timeout
+    while True:
+        try:
+            with open(path, "rb") as f:
+                blob = f.read()
+            if len(blob) == 128 + len(nonce) and blob[128:] == nonce:
+                return blob[:128]
+        except FileNotFoundError:
+            pass
+        if time.monotonic() > deadline:
+            raise TimeoutError(f"rank {rank}: no RCCL unique id of this job at {path} after {timeout:.0f} s")
+        time.sleep(0.01)
+
+
 def rendezvous(ctx, rank, world, path=None, timeout=300.0):
-    """One-process-per-GPU communicator: rank 0 makes the unique id (ncclGetUniqueId) and writes it atomically to `path`,
-    the others wait for the file; everyone then joins with ncclCommInitRank.  Returns an api.Comm."""
+    """One-process-per-GPU communicator: rank 0 makes the unique id (ncclGetUniqueId) and writes it, tagged with the job's
+    nonce, atomically to `path`; the others wait for a file with that nonce (a stale file of another job would make
+    ncclCommInitRank hang on a mismatched id); everyone then joins with ncclCommInitRank.  Returns an api.Comm."""
     from . import api
     path = path or rendezvous_path()
+    nonce = job_nonce()
     if rank == 0:
         uid = api.Comm.unique_id()
-        tmp = f"{path}.{os.getpid()}.tmp"
-        with open(tmp, "wb") as f:
-            f.write(uid)
-        os.replace(tmp, path)
+        publish_unique_id(path, uid, nonce)
     else:
-        deadline = time.monotonic() + timeout
-        while True:
-            try:
-                with open(path, "rb") as f:
-                    uid = f.read()
-                if len(uid) == 128:
-                    break
-            except FileNotFoundError:
-                pass
-            if time.monotonic() > deadline:
-                raise TimeoutError(f"rank {rank}: no RCCL unique id at {path} after {timeout:.0f} s")
-            time.sleep(0.01)
+        uid = wait_unique_id(path, nonce, timeout, rank)
     comm = api.Comm.init_rank(ctx, uid, rank, world)
     comm.barrier()   # everyone has read the file
     if rank == 0:
@@ -126,6 +157,29 @@ def rendezvous(ctx, rank, world, path=None, timeout=300.0):
         except OSError:
             pass
     return comm
+
+
+def gather_framebuffer_to(dist, ops, framebuffer, width, height, tile_size, rank, world, root=0):
+    """Host-logic twin of lupin_hip_gather_framebuffer_to: every rank but `root` sends its exact tile payload, the root
+    receives them and scatters.  Returns the payload bytes this rank sent (0 on the root)."""
+    torch = ops.torch
+    if rank == root:
+        for r in range(world):
+            if r == root:
+                continue
+            n = packed_pixels(width, height, tile_size, r, world)
+            if n == 0:
+                continue
+            buf = torch.empty(n, dtype=torch.int64)
+            dist.recv(buf, src=r)
+            ops.unpack(framebuffer, buf, tile_size, r, world)
+        if hasattr(ops, "finish"):
+            ops.finish()
+        return 0
+    n = packed_pixels(width, height, tile_size, rank, world)
+    if n:
+        dist.send(ops.pack(framebuffer, tile_size, rank, world, n), dst=root)
+    return n * 8
 
 
 def gather_framebuffer(dist, ops, framebuffer, width, height, tile_size, rank, world):

@@ -56,3 +56,51 @@ def test_gloo_gather_reproduces_single_process_render(built, tmp_path, world):
     z = np.load(out)
     assert np.array_equal(z["gathered"].view(np.uint16), z["full"].view(np.uint16))
     assert int(z["nbytes"]) >= 48 * 40 * 8 // world
+    # the readback form (gather_framebuffer_to): the root holds the whole frame, nobody else's framebuffer changed, and the
+    # payloads sent add up to exactly the pixels the root does not own
+    assert np.array_equal(z["gathered_to"].view(np.uint16), z["full"].view(np.uint16))
+    assert z["others_untouched"].all()
+    root = world - 1
+    assert int(z["sent"].sum()) == (48 * 40 - distributed.packed_pixels(48, 40, 2, root, world)) * 8 and int(z["sent"][root]) == 0
+
+
+def test_rendezvous_ignores_a_stale_file(built, tmp_path, monkeypatch):
+    """A leftover id file of a dead job (same path) must not be taken for this job's: readers match the job nonce."""
+    import threading
+    path = str(tmp_path / "rdzv")
+    monkeypatch.setenv("MASTER_PORT", "29999")
+    nonce = distributed.job_nonce()
+    assert len(nonce) == 32 and nonce == distributed.job_nonce()
+    monkeypatch.setenv("LUPIN_RDZV_NONCE", "another job")
+    stale_nonce = distributed.job_nonce()
+    assert stale_nonce != nonce
+    monkeypatch.delenv("LUPIN_RDZV_NONCE")
+    with open(path, "wb") as f:                      # what a job that died before its clean-up leaves behind
+        f.write(bytes(range(128)) + stale_nonce)
+    with pytest.raises(TimeoutError):
+        distributed.wait_unique_id(path, nonce, timeout=0.2, rank=1)
+    with open(path, "wb") as f:                      # a pre-nonce 128-byte file is not accepted either
+        f.write(bytes(128))
+    with pytest.raises(TimeoutError):
+        distributed.wait_unique_id(path, nonce, timeout=0.1, rank=1)
+    uid = bytes(reversed(range(128)))
+    t = threading.Timer(0.1, distributed.publish_unique_id, (path, uid, nonce))
+    t.start()
+    assert distributed.wait_unique_id(path, nonce, timeout=5.0, rank=1) == uid
+    t.join()
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash(built, tmp_path):
+    """LUPIN_RCCL_LIB names the library to load; one that cannot be loaded must come back as LUPIN_ERR_RCCL with dlopen's
+    message (the failure path once dereferenced a second dlerror() == NULL)."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from lupinpathtracer_amd import _abi\n"
+            "import ctypes as C\n"
+            "buf = (C.c_uint8 * 128)()\n"
+            "rc = _abi.lib().lupin_hip_comm_get_unique_id(C.cast(buf, C.c_void_p))\n"
+            "msg = _abi.lib().lupin_hip_last_error().decode()\n"
+            "print(rc, msg)\n"
+            "assert rc == -8 and 'librccl could not be loaded' in msg and 'no_such_rccl' in msg, (rc, msg)\n") % os.path.dirname(HERE)
+    env = dict(os.environ, LUPIN_RCCL_LIB=str(tmp_path / "no_such_rccl.so"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
