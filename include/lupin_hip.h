@@ -334,6 +334,14 @@ int lupin_hip_sync(LupinContext *ctx);
 #define LUPIN_STORE_ROUND_NEAREST_EVEN 1
 int lupin_hip_set_f16_store_rounding(LupinContext *ctx, int mode);
 
+/* Which hierarchy the persistent tracer walks on scenes traversed from global memory (DESIGN.md 5 "Wide traversal").
+ * WIDE (default): the four-wide collapse of the reference's trees with an exactness certificate; queries it cannot
+ * certify are re-traced in the reference's order (LupinStats.wide_queries / wide_retraced).  BINARY: the reference's
+ * own visiting order for every query.  Same images either way; LUPIN_TRAVERSAL=binary sets the default at context
+ * creation.  Takes effect with the next pathtrace call. */
+enum LupinTraversalMode { LUPIN_TRAVERSAL_WIDE = 0, LUPIN_TRAVERSAL_BINARY = 1 };
+int lupin_hip_set_traversal(LupinContext *ctx, int mode);
+
 /* lp::build_pathtrace_resources (renderer.rs:470-642): bakes max_bounces / samples_per_pixel */
 /* pathtracer.wgsl:275-289 accumulates into an Rgba16Float texture: the running mean is re-quantised to f16 every frame
  * (and stalls once 1/k drops under half an ulp).  LUPIN_ACCUM_F16_RUNNING_AVERAGE reproduces that bit for bit
@@ -449,6 +457,24 @@ typedef struct LupinStats {
     uint64_t node_visits[3];
     uint64_t tri_tests[3];
     uint64_t instance_entries[3];
+    uint64_t wide_node_visits[3];   /* visits of four-wide nodes (one 128-byte fetch each) */
+    /* how the persistent tracer's waves spent their scheduling rounds (closest-hit mode, first pass): refill rounds | node
+     * rounds, node steps, lanes summed over the node steps | triangle rounds, lanes | instance rounds, lanes | end-of-
+     * traversal rounds, lanes.  lanes / (64 x steps or rounds) = lane utilisation of that phase. */
+    uint64_t tracer_rounds[10];
+    /* shader-clock cycles (s_memtime, summed over the waves) spent in refill | node | triangle | instance | end-of-traversal
+     * rounds and in the whole scheduling loop (the work-counting build waits for each round's loads before reading the clock) */
+    uint64_t tracer_cycles[6];
+    /* The wide tracer (always counted): closest-hit queries it took, and how many of them it could not certify and handed
+     * to the binary tracer (the reference's visiting order) -- the fallback rate is wide_retraced / wide_queries. */
+    uint64_t wide_queries;
+    uint64_t wide_retraced;
+    /* LUPIN_VERIFY_WIDE=1: every query also run binary-vs-wide on the device, one ray per lane: rays checked, rays the wide
+     * traversal flagged, unflagged rays whose result differed (must be 0), rays that differed flag or not */
+    uint64_t verify_checked, verify_flagged, verify_mismatches, verify_raw_mismatches;
+    uint64_t verify_reasons[4];     /* flagged rays by reason: second hit within the margin | ill-conditioned hit | triangle outside a box above it | stack bound */
+    uint32_t frames_in_flight;      /* lanes the latest pathtrace call could use */
+    uint32_t wide_traversal;        /* 1 = the latest pathtrace call ran the four-wide tracer */
 } LupinStats;
 enum LupinStatsMode {
     LUPIN_STATS_PLAIN = 0,           /* path-bounce / path counters only (always on) */
@@ -481,6 +507,16 @@ int lupin_hip_trace_rays(LupinContext *ctx, const LupinScene *scene, uint32_t n,
                          const float *ori_xyz, const float *dir_xyz, float ray_epsilon,
                          uint32_t *out_hit, float *out_dst, float *out_uv,
                          uint32_t *out_instance, uint32_t *out_tri);
+
+/* The same probe through the four-wide traversal the persistent tracer runs by default on scenes traversed from global
+ * memory (DESIGN.md 5 "Wide traversal"): out_needs_retrace[i] = 1 when the traversal could not certify that ray's result
+ * (the pipeline re-traces such a query with the binary kernel; the other outputs of that ray are then unspecified);
+ * every other ray's outputs equal lupin_hip_trace_rays' bit for bit.  Scenes staged in LDS have no wide hierarchy
+ * (LUPIN_ERR_INVALID_ARGUMENT). */
+int lupin_hip_trace_rays_wide(LupinContext *ctx, const LupinScene *scene, uint32_t n,
+                              const float *ori_xyz, const float *dir_xyz, float ray_epsilon,
+                              uint32_t *out_hit, float *out_dst, float *out_uv,
+                              uint32_t *out_instance, uint32_t *out_tri, uint32_t *out_needs_retrace);
 
 /* Evaluates one function of include/lupin_detmath.h (fn: 0 sin, 1 cos, 2 atan, 3 atan2(x,y), 4 acos,
  * 5 exp, 6 log, 7 pow(x,y), 8 x/y, 9 sqrt) on the device over host arrays; the tests require the
@@ -578,6 +614,20 @@ int64_t lupin_hip_build_bvh_device(LupinContext *ctx, const float *verts_pos4, u
  * 2 * triangles - 1 nodes always suffice; vertex positions must be finite).  Synchronous. */
 int64_t lupin_hip_build_bvh_sah_device(LupinContext *ctx, const float *verts_pos4, uint32_t num_verts, uint32_t *indices,
                                        uint32_t num_indices, LupinBvhNode *out_nodes, uint64_t out_capacity);
+
+/* The four-wide collapse of one mesh's BLAS exactly as lupin_hip_scene_create performs it for the wide tracer (host code,
+ * no device needed; DESIGN.md 5 "Wide traversal"): a node's grandchildren are pulled up, largest box first, until it has
+ * four children or only leaves; a child whose own children's boxes are not inside its box stays a child.  out_nodes
+ * receives 128-byte records of 32 words: lox[4] loy[4] loz[4] hix[4] hiy[4] hiz[4] (f32; NaN in unused slots), ref[4]
+ * (u32: bit 31 = leaf, bit 30 = the child's box does not contain every triangle below it (never pruned by distance), low
+ * 30 bits = first triangle of the leaf / index into out_nodes; 0xFFFFFFFF = unused slot), 4 zero words.
+ * With vertex data (verts_pos4 / indices in BLAS leaf order; may be NULL), out_tri_flags (may be NULL; one byte per
+ * triangle) receives bit 0 = last triangle of its leaf, bit 1 = the triangle is not inside every box above it.
+ * Returns the node count (out_nodes may be NULL to query it) or < 0; *out_root = the root reference (a single-leaf BLAS
+ * has no wide node: the leaf reference passes through). */
+int64_t lupin_hip_collapse_bvh4(const LupinBvhNode *nodes, uint32_t num_nodes, const float *verts_pos4, uint32_t num_verts,
+                                const uint32_t *indices, uint32_t num_indices, void *out_nodes, uint64_t capacity,
+                                uint32_t *out_root, uint8_t *out_tri_flags);
 
 /* build_bvh (data_structures.rs:196-235): reorders `indices` in place; returns node count or <0.
  * out_nodes may be NULL to query the count (indices untouched in that case). */

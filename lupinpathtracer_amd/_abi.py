@@ -135,7 +135,11 @@ class TonemapDescC(C.Structure):
 class StatsC(C.Structure):
     _fields_ = [("path_bounces", C.c_uint64), ("paths", C.c_uint64), ("extend_launches", C.c_uint64),
                 ("extend_ms", C.c_double), ("shade_ms", C.c_double), ("total_ms", C.c_double),
-                ("node_visits", C.c_uint64 * 3), ("tri_tests", C.c_uint64 * 3), ("instance_entries", C.c_uint64 * 3)]
+                ("node_visits", C.c_uint64 * 3), ("tri_tests", C.c_uint64 * 3), ("instance_entries", C.c_uint64 * 3),
+                ("wide_node_visits", C.c_uint64 * 3), ("tracer_rounds", C.c_uint64 * 10), ("tracer_cycles", C.c_uint64 * 6), ("wide_queries", C.c_uint64), ("wide_retraced", C.c_uint64),
+                ("verify_checked", C.c_uint64), ("verify_flagged", C.c_uint64), ("verify_mismatches", C.c_uint64),
+                ("verify_raw_mismatches", C.c_uint64), ("verify_reasons", C.c_uint64 * 4), ("frames_in_flight", C.c_uint32),
+                ("wide_traversal", C.c_uint32)]
 
 
 class RuntimeInfoC(C.Structure):
@@ -155,6 +159,7 @@ SYMBOLS = [
     ("lupin_hip_sync", C.c_int, [_P]),
     ("lupin_hip_set_f16_store_rounding", C.c_int, [_P, C.c_int]),
     ("lupin_hip_set_accumulation_mode", C.c_int, [_P, C.c_int]),
+    ("lupin_hip_set_traversal", C.c_int, [_P, C.c_int]),
     ("lupin_hip_reserve_path_state", C.c_int, [_P, C.c_uint64, _U32, _U32]),
     ("lupin_hip_texture_download_rgba32f", C.c_int, [_P, _P]),
     ("lupin_hip_measure_copy_bandwidth", C.c_int, [_P, C.c_uint64, _U32, C.POINTER(C.c_double)]),
@@ -185,6 +190,8 @@ SYMBOLS = [
     ("lupin_hip_stats_reset", C.c_int, [_P, C.c_int]),
     ("lupin_hip_stats_get", C.c_int, [_P, C.POINTER(StatsC)]),
     ("lupin_hip_trace_rays", C.c_int, [_P, _P, _U32, _P, _P, C.c_float, _P, _P, _P, _P, _P]),
+    ("lupin_hip_collapse_bvh4", C.c_int64, [_P, _U32, _P, _U32, _P, _U32, _P, C.c_uint64, C.POINTER(C.c_uint32), _P]),
+    ("lupin_hip_trace_rays_wide", C.c_int, [_P, _P, _U32, _P, _P, C.c_float, _P, _P, _P, _P, _P, _P]),
     ("lupin_hip_detmath_probe", C.c_int, [_P, C.c_int, _U32, _P, _P, _P]),
     ("lupin_hip_tonemap_and_fit_aspect", C.c_int, [_P, _P, _P, _U32, _U32, C.POINTER(TonemapDescC)]),
     ("lupin_hip_lbvh_depth", _U32, [_U32]),

@@ -185,6 +185,10 @@ class Context:
         """Allocate the path state of every frame in flight now instead of at each lane's first pathtrace call."""
         check(lib().lupin_hip_reserve_path_state(self.handle, int(pixels), int(max_bounces), int(samples_per_pixel)))
 
+    def set_traversal(self, mode):
+        """"wide" (default: four-wide hierarchy + exactness certificate + re-trace) or "binary" (the reference's order only)."""
+        check(lib().lupin_hip_set_traversal(self.handle, {"wide": 0, "binary": 1}[mode]))
+
     def set_accumulation_mode(self, mode):
         """0 = f16 running average (reference-faithful, default), 1 = f32 accumulator per texture (pathtracer.wgsl:275-289)."""
         check(lib().lupin_hip_set_accumulation_mode(self.handle, int(mode)))
@@ -885,3 +889,20 @@ def trace_rays(ctx, scene, ori, dir_, ray_epsilon=0.001):
     check(lib().lupin_hip_trace_rays(ctx.handle, scene.handle, n, ptr(ori), ptr(dir_), ray_epsilon,
                                      ptr(hit), ptr(dst), ptr(uv), ptr(inst), ptr(tri)))
     return hit, dst, uv, inst, tri
+
+
+def trace_rays_wide(ctx, scene, ori, dir_, ray_epsilon=0.001):
+    """The same probe through the four-wide traversal: returns hit, dst, uv, instance, tri and `needs_retrace` (1 = the
+    traversal could not certify that ray; the pipeline re-traces such queries with the binary kernel)."""
+    ori = np.ascontiguousarray(ori, np.float32).reshape(-1, 3)
+    dir_ = np.ascontiguousarray(dir_, np.float32).reshape(-1, 3)
+    n = len(ori)
+    hit = np.zeros(n, np.uint32)
+    dst = np.zeros(n, np.float32)
+    uv = np.zeros((n, 2), np.float32)
+    inst = np.zeros(n, np.uint32)
+    tri = np.zeros(n, np.uint32)
+    flag = np.zeros(n, np.uint32)
+    check(lib().lupin_hip_trace_rays_wide(ctx.handle, scene.handle, n, ptr(ori), ptr(dir_), ray_epsilon,
+                                          ptr(hit), ptr(dst), ptr(uv), ptr(inst), ptr(tri), ptr(flag)))
+    return hit, dst, uv, inst, tri, flag

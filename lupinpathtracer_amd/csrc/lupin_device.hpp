@@ -38,6 +38,7 @@ namespace lpd {
 //   TLAS: bit31 set   -> leaf, low 31 bits = instance index
 constexpr uint32_t REF_LEAF = 0x80000000u;
 constexpr uint32_t LEAF_END_BITS = 1u;
+constexpr uint32_t TRI_LEAKY_BITS = 2u;   // TriVerts.v0.w: the triangle is not inside every box the reference's BLAS stores above it
 
 // One internal node = both children's boxes + references, one 64-byte line.  The reference
 // reads the node (32/48 B) and then both children (2 x 32/48 B) per visit
@@ -49,6 +50,25 @@ struct WideNode
     float4 b;  // l.max.y l.max.z r.min.x r.min.y
     float4 c;  // r.min.z r.max.x r.max.y r.max.z
     uint4 d;   // left_ref right_ref 0 0
+};
+
+// The same hierarchies collapsed to four children per node (lupin_hip_scene_create: a node's grandchildren are pulled up,
+// largest box first, until it has four children or only leaves): one 128-byte line = one L1-miss request, which costs the
+// memory system what a 64-byte one does (profiles/r02_gather_probe.jsonl), and a ray needs about half as many of them.
+// Child k's box is the box the reference's tree stores for that node; an unused slot holds NaN bounds (its slab test
+// misses) and REF_NONE.  TLAS and BLAS nodes share ONE array (no per-lane base select in the traversal step).
+// Child references: bit 31 = leaf (as in WideNode.d), bit 30 = REF_LEAKY: the child's stored box does not bound every
+// triangle below it (never pruned by distance, see "Wide traversal" below), low 30 bits = node index / first triangle /
+// instance.  Traversed by the wide tracer only (k_extend_persistent<.., WIDE>, scene_closest_wide).
+constexpr uint32_t REF_NONE = 0xFFFFFFFFu;
+constexpr uint32_t REF_LEAKY = 0x40000000u;
+constexpr uint32_t REF_INDEX_MASK = 0x3FFFFFFFu;
+struct __attribute__((aligned(128))) Wide4
+{
+    float4 lox, loy, loz;   // children 0..3: min corner, one axis per word
+    float4 hix, hiy, hiz;   // max corner
+    uint4 ref;              // child references
+    uint4 pad;              // not read by the traversal
 };
 
 // Triangles pre-gathered in BLAS leaf order: no index indirection during traversal
@@ -109,6 +129,10 @@ struct SceneDev
     const LupinAliasBin *alias_bins;     // pool
     uint32_t num_lights, num_envs, num_instances;
     uint32_t sort_shade;                 // k_shade sorts each block's paths by material type (scenes with > 1 type)
+    // four-wide collapse of the same two hierarchies in one array (wide tracer); inst_root4[i] = wide BLAS root reference of instance i
+    const Wide4 *wide4;
+    const uint32_t *inst_root4;
+    uint32_t tlas4_root;
     // small scenes: [tlas | blas | tris | instances] as one array of 16-byte words that kernels stage in LDS
     const float4 *geo_blob;
     uint32_t geo_blob_words;                       // 0 = scene too large, traverse from global memory
@@ -263,6 +287,16 @@ struct GeoGlobal
     LP_DEV TriVerts tri(uint32_t i) const { return tris[i]; }           // a triangle TEST fetches through tri()
     LP_DEV TriVerts tri_fetch(uint32_t i) const { return tris[i]; }     // shading re-reads vertices through tri_fetch()
     LP_DEV InstanceDev inst(uint32_t i) const { return instances[i]; }
+    const Wide4 *wide4;
+    const uint32_t *inst_root4;
+    struct Node4 { float4 lox, loy, loz, hix, hiy, hiz; uint4 ref; };   // the 112 bytes of a Wide4 the traversal reads
+    LP_DEV Node4 node4(uint32_t i) const
+    {
+        const Wide4 *w = wide4 + i;
+        Node4 n; n.lox = w->lox; n.loy = w->loy; n.loz = w->loz; n.hix = w->hix; n.hiy = w->hiy; n.hiz = w->hiz; n.ref = w->ref;
+        return n;
+    }
+    LP_DEV uint32_t root4(uint32_t inst) const { return inst_root4[inst]; }
     static constexpr bool kCounting = false;
 };
 
@@ -318,9 +352,11 @@ template <typename Base>
 struct GeoTally
 {
     Base base;
-    uint32_t *tally;   // [0] node visits, [1] triangle tests, [2] instance entries
+    uint32_t *tally;   // [0] node visits, [1] triangle tests, [2] instance entries, [3] four-wide node visits (128 bytes each)
     static constexpr bool kCounting = false;   // light culling stays on: the tally is of the work actually done
     LP_DEV NodeRegs node(bool in_blas, uint32_t i) const { tally[0] += 1u; return base.node(in_blas, i); }
+    LP_DEV GeoGlobal::Node4 node4(uint32_t i) const { tally[3] += 1u; return base.node4(i); }
+    LP_DEV uint32_t root4(uint32_t inst) const { return base.root4(inst); }
     LP_DEV TriVerts tri(uint32_t i) const { tally[1] += 1u; return base.tri(i); }
     LP_DEV TriVerts tri_fetch(uint32_t i) const { return base.tri_fetch(i); }
     LP_DEV InstanceDev inst(uint32_t i) const { tally[2] += 1u; return base.inst(i); }
@@ -329,6 +365,7 @@ struct GeoTally
 LP_DEV GeoGlobal geo_global(const SceneDev &sc)
 {
     GeoGlobal g; g.tlas = sc.tlas; g.blas = sc.blas; g.tris = sc.tris; g.instances = sc.instances;
+    g.wide4 = sc.wide4; g.inst_root4 = sc.inst_root4;
     return g;
 }
 // Cooperative copy of the geometry blob into LDS at `words` (16-byte aligned); caller synchronises.
@@ -488,6 +525,210 @@ LP_DEV Closest scene_closest(const Geo &geo, const SceneDev &sc, uint32_t *stack
                 const TriVerts tv = geo.tri(ti);
                 TriHit h = tri_dst(co, cd, xyz(tv.v0), xyz(tv.v1), xyz(tv.v2), eps);
                 if (h.t < best.t) { best.t = h.t; best.u = h.u; best.v = h.v; best.tri = ti; best.inst = cur_inst; }
+                if (__float_as_uint(tv.v0.w) & LEAF_END_BITS) break;
+                ti++;
+            }
+            pop();
+        }
+    }
+    return best;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wide traversal with an exactness certificate.
+//
+// The reference's closest hit is order-dependent only in its margins: `best` is the FIRST tested triangle that attains the
+// minimum t over the triangles the traversal tested, and a subtree is skipped when its box's entry distance is not below
+// the best t AT THAT MOMENT (bvh_custom.wgsl:63-94, :221, :252-283).  A traversal that visits the same boxes in another
+// order returns the same triangle unless (a) two different triangles are hit at (nearly) the same t -- then visiting order
+// decides which one is kept, and which boxes the kept one's t prunes -- or (b) a triangle's computed t is not consistent
+// with the boxes around it, so that one order prunes it and another does not: an ill-conditioned intersection, or a
+// triangle that is not inside the boxes the reference's tree stores above it (they exist: lupin_hip.hip, collapse_to_wide4).
+//
+// The four-wide traversal below therefore (1) prunes with a MARGIN: a child is entered while its entry distance is below
+// wide_threshold(best.t) = best.t (1 + 2^-10) + abs_margin, so every triangle whose boxes are consistent with a t inside the
+// margin above the final best IS tested; (2) raises `flag` when it tests a second triangle hit inside that margin of the
+// current best, or a hit whose intersection is ill-conditioned (wide_hit_is_ill_conditioned) or whose triangle is marked as
+// outside a box above it (TRI_LEAKY_BITS), or when its bounded stack would overflow; (3) never prunes by distance a child
+// whose box does not bound its triangles (Wide4.pad.x).  An unflagged ray's (t, u, v, triangle, instance) is the reference's: with m' the conditioning bound and
+// (1 + m')^2 < 1 + m, the reference's winner R and this traversal's winner W each pass the other's pruning (their boxes'
+// entry distances are below t_W (1 + m) resp. the reference's best at every moment), so both traversals test both; W != R
+// would be a second hit inside the margin -> flagged.  Flagged rays are re-traced by the binary kernel, which IS the
+// reference's order.  What the certificate assumes is stated where it is used: DESIGN.md 5 "Wide traversal".
+// ------------------------------------------------------------------------------------------------
+
+// why a query is handed to the binary tracer (diagnostics: LUPIN_VERIFY_WIDE counts them)
+enum : uint32_t { WIDE_WHY_TIE = 1u, WIDE_WHY_CONDITION = 2u, WIDE_WHY_LEAKY = 4u, WIDE_WHY_STACK = 8u };
+constexpr float LP_WIDE_REL = 1.0f + 0x1p-10f;
+LP_DEV float wide_threshold(float best_t, float abs_margin)
+{
+    return __builtin_fminf(best_t * LP_WIDE_REL + abs_margin, LP_F32_MAX);   // best_t == MAX -> inf -> MAX: a miss (MAX) never passes
+}
+
+// Slab tests of a node's four children + sorting network by entry distance (children failing `d < thr` sort last as +inf).
+// Returns the number of children to visit; dk / rk hold them nearest first.  The slab arithmetic is slab_dst's, operation
+// for operation (same IEEE subtractions, multiplications, minNum / maxNum), written on pairs of children so that the
+// subtractions and multiplications issue as packed instructions (v_pk_add_f32 / v_pk_mul_f32: two IEEE results each).
+typedef float lp_v2 __attribute__((ext_vector_type(2)));
+// slab_dst's verdict from the six per-axis distances, as the child's sort key: dst_near when the slab test hits, +inf when
+// it misses (slab_dst returns MAX there; every use below only asks "below the threshold?" / "hit at all?").  Three chained
+// selects: each comparison feeds its own select, no mask arithmetic.
+LP_DEV float slab_key(float tminx, float tmaxx, float tminy, float tmaxy, float tminz, float tmaxz)
+{
+    float t1x = __builtin_fminf(tminx, tmaxx), t1y = __builtin_fminf(tminy, tmaxy), t1z = __builtin_fminf(tminz, tmaxz);
+    float t2x = __builtin_fmaxf(tminx, tmaxx), t2y = __builtin_fmaxf(tminy, tmaxy), t2z = __builtin_fmaxf(tminz, tmaxz);
+    float dst_far = __builtin_fminf(__builtin_fminf(t2x, t2y), t2z);
+    float dst_near = __builtin_fmaxf(__builtin_fmaxf(t1x, t1y), t1z);
+    float key = dst_far >= dst_near ? dst_near : __builtin_inff();
+    key = dst_far > 0.0f ? key : __builtin_inff();
+    return key;
+}
+// Fills dk / rk with the node's children, nearest first; a child that is not to be visited has dk = +inf (and sorts last).
+LP_DEV void wide_children(const GeoGlobal::Node4 &nd, f3 co, f3 cinv, float thr, float (&dk)[4], uint32_t (&rk)[4])
+{
+    const lp_v2 ox = {co.x, co.x}, oy = {co.y, co.y}, oz = {co.z, co.z};
+    const lp_v2 ix = {cinv.x, cinv.x}, iy = {cinv.y, cinv.y}, iz = {cinv.z, cinv.z};
+    #define LP_PAIR(v, a, b) (lp_v2){(v).a, (v).b}
+    const lp_v2 lx01 = (LP_PAIR(nd.lox, x, y) - ox) * ix, lx23 = (LP_PAIR(nd.lox, z, w) - ox) * ix;
+    const lp_v2 ly01 = (LP_PAIR(nd.loy, x, y) - oy) * iy, ly23 = (LP_PAIR(nd.loy, z, w) - oy) * iy;
+    const lp_v2 lz01 = (LP_PAIR(nd.loz, x, y) - oz) * iz, lz23 = (LP_PAIR(nd.loz, z, w) - oz) * iz;
+    const lp_v2 hx01 = (LP_PAIR(nd.hix, x, y) - ox) * ix, hx23 = (LP_PAIR(nd.hix, z, w) - ox) * ix;
+    const lp_v2 hy01 = (LP_PAIR(nd.hiy, x, y) - oy) * iy, hy23 = (LP_PAIR(nd.hiy, z, w) - oy) * iy;
+    const lp_v2 hz01 = (LP_PAIR(nd.hiz, x, y) - oz) * iz, hz23 = (LP_PAIR(nd.hiz, z, w) - oz) * iz;
+    #undef LP_PAIR
+    float hit[4];   // entry distance, +inf = the ray misses the box (NaN bounds of an unused slot miss)
+    hit[0] = slab_key(lx01.x, hx01.x, ly01.x, hy01.x, lz01.x, hz01.x);
+    hit[1] = slab_key(lx01.y, hx01.y, ly01.y, hy01.y, lz01.y, hz01.y);
+    hit[2] = slab_key(lx23.x, hx23.x, ly23.x, hy23.x, lz23.x, hz23.x);
+    hit[3] = slab_key(lx23.y, hx23.y, ly23.y, hy23.y, lz23.y, hz23.y);
+    rk[0] = nd.ref.x; rk[1] = nd.ref.y; rk[2] = nd.ref.z; rk[3] = nd.ref.w;
+    #pragma unroll
+    for (int k = 0; k < 4; k++) dk[k] = hit[k] < thr ? hit[k] : __builtin_inff();
+    // A child whose box does not bound its triangles (REF_LEAKY; one triangle in 4 x 10^5 on the bistro-class meshes) is entered
+    // whenever the ray passes the box, however far: a triangle below may lie in front of it; its recorded distance is -inf
+    // so that no pop drops it either.  Rare: one test per node, the per-child work only in the lanes it applies to.
+    if (((rk[0] | rk[1] | rk[2] | rk[3]) & REF_LEAKY) && (rk[0] & rk[1] & rk[2] & rk[3]) != REF_NONE)
+    {
+        #pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (rk[k] != REF_NONE && (rk[k] & REF_LEAKY)) dk[k] = hit[k] < __builtin_inff() ? -__builtin_inff() : __builtin_inff();
+    }
+    auto cswap = [&](int a, int b) {
+        const bool sw = dk[b] < dk[a];
+        const float da = dk[a], db = dk[b];
+        const uint32_t ra = rk[a], rb = rk[b];
+        dk[a] = sw ? db : da; dk[b] = sw ? da : db;
+        rk[a] = sw ? rb : ra; rk[b] = sw ? ra : rb;
+    };
+    cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2);
+}
+
+// Is the computed t of this hit too uncertain to be trusted against the boxes around the triangle?  With e1, e2 the edges,
+// r = o - v0, n = e1 x e2:  t = -(n.r) / (d.n); the absolute errors of the two dot products are below 12 u |e1||e2||r| and
+// 12 u |e1||e2||d| (u = 2^-24), so |t - t_exact| < 12 u (A1 + A2) + 2 u t with A1 = |e1||e2||r| / |d.n|, A2 = t |e1||e2||d| / |d.n|.
+// The certificate tolerates an error of m' t + a' (m' = 2^-12: (1 + m')^2 < 1 + 2^-10 with room for the slab test's own
+// three roundings; a' = a quarter of the absolute margin): each of A1, A2 must stay below L / 2, L = (m' t + a') / (12 u).
+// Squared, so no root or division; the comparisons are written so that zero / NaN / inf flag.
+LP_DEV bool wide_hit_is_ill_conditioned(f3 o, f3 d, f3 v0, f3 v1, f3 v2, float t, float abs_margin)
+{
+    const f3 e1 = sub(v1, v0), e2 = sub(v2, v0), r = sub(o, v0);
+    const f3 n = cross3(e1, e2);
+    const float det = dot3(d, n);
+    const float ee = dot3(e1, e1) * dot3(e2, e2);
+    const float L = (0x1p-12f * t + 0.25f * abs_margin) * (0x1p24f / 12.0f);
+    const float budget = (L * det) * (L * det);
+    const bool ok1 = 4.0f * (ee * dot3(r, r)) <= budget;
+    const bool ok2 = 4.0f * ((t * t) * (ee * dot3(d, d))) <= budget;
+    return !(ok1 && ok2);
+}
+
+// One triangle test of the wide traversal: updates `best` exactly like the reference's test and returns whether the ray
+// must be re-traced in the reference's order (second hit within the margin of the best, or an untrustworthy hit).
+LP_DEV bool wide_test_triangle(const TriVerts &tv, uint32_t ti, uint32_t inst, f3 co, f3 cd, float eps, float abs_margin, Closest &best, uint32_t *why = nullptr)
+{
+    const TriHit h = tri_dst(co, cd, xyz(tv.v0), xyz(tv.v1), xyz(tv.v2), eps);
+    bool flag = false;
+    if (h.t != LP_F32_MAX && h.t == h.t)   // a hit candidate (NaN never wins in any order)
+    {
+        const float lo = minf(h.t, best.t), hi = maxf(h.t, best.t);
+        const bool relevant = hi <= wide_threshold(lo, abs_margin);   // within the margin of the current best (always false while best is MAX)
+        if (best.t != LP_F32_MAX && relevant) { flag = true; if (why) *why |= WIDE_WHY_TIE; }
+        if (relevant || h.t < best.t)
+        {
+            if (__float_as_uint(tv.v0.w) & TRI_LEAKY_BITS) { flag = true; if (why) *why |= WIDE_WHY_LEAKY; }
+            if (wide_hit_is_ill_conditioned(co, cd, xyz(tv.v0), xyz(tv.v1), xyz(tv.v2), h.t, abs_margin)) { flag = true; if (why) *why |= WIDE_WHY_CONDITION; }
+        }
+        if (h.t < best.t) { best.t = h.t; best.u = h.u; best.v = h.v; best.tri = ti; best.inst = inst; }
+    }
+    return flag;
+}
+
+// ray_scene_intersection over the four-wide hierarchies, one ray per lane (probes and the verification kernel; the hot
+// path runs the same steps phase-scheduled in k_extend_persistent<.., WIDE>).  Stack: `entries` (reference, entry
+// distance) pairs per lane at stack[(2 e + {0, 1}) * LP_BLOCK + tid]; a popped entry whose recorded distance is no longer
+// below the threshold is dropped without fetching its node.  `flag` = the result may differ from the reference's (re-trace).
+template <typename Geo>
+LP_DEV Closest scene_closest_wide(const Geo &geo, const SceneDev &sc, uint32_t *stack, uint32_t entries, f3 o, f3 d, float eps, bool &flag, uint32_t *why = nullptr)
+{
+    const uint32_t tid = threadIdx.x;
+    constexpr uint32_t REF_DONE = 0xFFFFFFFFu;
+    const float abs_margin = 0.25f * eps;
+    Closest best;
+    best.t = LP_F32_MAX; best.u = 0.0f; best.v = 0.0f; best.tri = 0u; best.inst = 0xFFFFFFFFu;
+    flag = false;
+    if (sc.num_instances == 0) return best;
+    const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    f3 co = o, cd = d, cinv = inv_d;
+    uint32_t sp = 0, blas_base = 0xFFFFFFFFu, cur_inst = 0, cur = sc.tlas4_root;
+
+    auto pop = [&]() {
+        const float thr = wide_threshold(best.t, abs_margin);
+        for (;;)
+        {
+            if (sp == blas_base) { blas_base = 0xFFFFFFFFu; co = o; cd = d; cinv = inv_d; }
+            if (sp == 0) { cur = REF_DONE; return; }
+            sp--;
+            const float sd = __uint_as_float(stack[(2u * sp + 1u) * LP_BLOCK + tid]);
+            if (sd < thr) { cur = stack[(2u * sp) * LP_BLOCK + tid]; return; }
+        }
+    };
+
+    for (;;)
+    {
+        while (!(cur & REF_LEAF))
+        {
+            const auto nd = geo.node4(cur & REF_INDEX_MASK);
+            float dk[4]; uint32_t rk[4];
+            wide_children(nd, co, cinv, wide_threshold(best.t, abs_margin), dk, rk);
+            if (sp + 3u > entries) { flag = true; if (why) *why |= WIDE_WHY_STACK; return best; }   // bounded stack (room for three is required): hand the ray to the binary tracer
+            #pragma unroll
+            for (int k = 3; k >= 1; k--)
+                if (dk[k] < __builtin_inff()) { stack[(2u * sp) * LP_BLOCK + tid] = rk[k]; stack[(2u * sp + 1u) * LP_BLOCK + tid] = __float_as_uint(dk[k]); sp++; }
+            if (dk[0] < __builtin_inff()) cur = rk[0]; else pop();
+        }
+        if (cur == REF_DONE) break;
+        if (blas_base == 0xFFFFFFFFu)
+        {
+            cur_inst = cur & REF_INDEX_MASK;
+            const InstanceDev in = geo.inst(cur_inst);
+            co = mk3(o.x * in.r0.x + o.y * in.r0.y + o.z * in.r0.z + 1.0f * in.r0.w,
+                     o.x * in.r1.x + o.y * in.r1.y + o.z * in.r1.z + 1.0f * in.r1.w,
+                     o.x * in.r2.x + o.y * in.r2.y + o.z * in.r2.z + 1.0f * in.r2.w);
+            cd = mk3(d.x * in.r0.x + d.y * in.r0.y + d.z * in.r0.z + 0.0f * in.r0.w,
+                     d.x * in.r1.x + d.y * in.r1.y + d.z * in.r1.z + 0.0f * in.r1.w,
+                     d.x * in.r2.x + d.y * in.r2.y + d.z * in.r2.z + 0.0f * in.r2.w);
+            const uint32_t root = geo.root4(cur_inst);
+            if (!(root & REF_LEAF)) cinv = mk3(1.0f / cd.x, 1.0f / cd.y, 1.0f / cd.z);
+            blas_base = sp;
+            cur = root;
+        }
+        else
+        {
+            uint32_t ti = cur & REF_INDEX_MASK;
+            for (;;)
+            {
+                const TriVerts tv = geo.tri(ti);
+                if (wide_test_triangle(tv, ti, cur_inst, co, cd, eps, abs_margin, best, why)) flag = true;
                 if (__float_as_uint(tv.v0.w) & LEAF_END_BITS) break;
                 ti++;
             }

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <string>
 #include <vector>
 #include <set>
@@ -31,7 +32,9 @@ static int fail(int code, const std::string &msg) { g_last_error = msg; return c
 #define HIP_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return fail(LUPIN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } while (0)
 
 #define LP_MAX_LANES 8
-#define LP_WORK_WORDS 12   // 3 tracing modes (closest hit | shadow rays | light-pdf marching) x {nodes, triangles, instances}, padded
+#define LP_WIDE_WORDS 10   // [0] wide queries, [1] re-traced, [2..9] LUPIN_VERIFY_WIDE: checked, flagged, mismatches among unflagged, raw mismatches, 4 reasons
+#define LP_COUNTER_ROWS 7   // per iteration and shard: 1 queue counter + 2 hand-out cursors + 2 re-trace counters + 2 re-trace cursors
+#define LP_WORK_WORDS 28   // 3 tracing modes (closest hit | shadow rays | light-pdf marching) x {nodes, triangles, instances, four-wide nodes}, then 10 round statistics
 // "Lanes" (stream + path buffers + counters) let consecutive pathtrace_scene calls overlap: the wavefront of
 // frame k+1 starts while the thin tail of frame k is still draining.  Frames only meet at k_resolve (frame k+1 blends
 // with frame k's output), which waits on the previous call's completion event.
@@ -45,7 +48,8 @@ struct Lane
     uint64_t capacity = 0;          // slots the path buffers hold
     uint32_t counts_capacity = 0;
     unsigned long long *stat_counters = nullptr;   // per shard: [2s] path bounces, [2s+1] paths
-    unsigned long long *work_counters = nullptr;   // [3 * mode + {nodes, triangles, instances}] of the COUNT kernels (stats mode 2)
+    unsigned long long *work_counters = nullptr;   // [4 * mode + {nodes, triangles, instances, wide nodes}] of the COUNT kernels (stats mode 2)
+    unsigned long long *wide_counters = nullptr;   // [0] queries the wide tracer took, [1] queries re-traced by the binary tracer
     hipEvent_t done = nullptr;      // recorded after the last kernel of the lane's latest call
     bool used = false;
     FrameParams *d_fp = nullptr;    // this lane's per-call parameters (k_set_params writes, the stage kernels read)
@@ -55,6 +59,7 @@ struct Lane
     {
         uint64_t scene_id = 0, pb_generation = 0;
         uint32_t n = 0, blocks = 0, type = 0, iterations = 0, stack_words = 0, lds = 0, pblocks = 0, refill_min = 0, node_steps = 0;
+        uint32_t wide_blocks = 0, wide_stack_words = 0;
         int persistent = 0, persistent_shadow = 0, lds_geometry = 0;
         bool operator==(const GraphKey &o) const { return memcmp(this, &o, sizeof(GraphKey)) == 0; }
     } graph_key, seen_key;           // key of graph_exec | key of the lane's previous call
@@ -90,9 +95,14 @@ struct LupinContext
     bool use_graph = false;                 // LUPIN_GRAPH=1: replay the lane-private wavefront as a HIP graph (opt-in)
     bool persistent_shadow = true;          // LUPIN_SHADOW=simple: MIS / Direct shadow rays stay in k_shadow even on large scenes
     uint32_t node_steps = 4;               // LUPIN_NODE_STEPS: node visits per scheduling round of k_extend_persistent
+    bool wide_traversal = true;            // LUPIN_TRAVERSAL=binary: the persistent tracer walks the reference's binary hierarchy only
+    uint32_t wide_stack_pairs = 20;        // LUPIN_WIDE_STACK: (reference, distance) stack entries per lane of the wide tracer
+    bool verify_wide = false;              // LUPIN_VERIFY_WIDE=1: every closest-hit query is also checked wide-vs-binary on the device (stats)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_extend, ev_shade, ev_total;
     std::vector<hipEvent_t> ev_pool;
     uint64_t extend_launches = 0;
+    int last_lanes = 0;                    // frames in flight the latest pathtrace call could use (reported by lupin_hip_stats_get)
+    bool last_wide = false;                // ... and whether it ran the four-wide tracer
 };
 
 struct LupinPathtraceResources
@@ -116,6 +126,9 @@ struct LupinScene
     std::vector<void *> allocations;
     uint32_t stack_entries = 1;
     uint32_t persistent_blocks[4] = {0, 0, 0, 0};   // grid of k_extend_persistent per integrator (lazy)
+    uint32_t wide_blocks[4] = {0, 0, 0, 0};         // grid of its four-wide instantiation
+    bool has_wide = false;                          // the four-wide hierarchies were built (scenes traversed from global memory)
+    uint64_t leaky_triangles = 0;                   // triangles outside some box above them (reference builder: bins vs partition)
     uint64_t id = 0;                                // unique per created scene (graph cache key)
     bool all_opaque = false;                        // no instance can have opacity != 1: k_extend<.., OPAQUE> drops the alpha test
     bool simple_matte = false;                      // only untextured matte materials, no vertex colours, no environments: k_shade<.., SIMPLE>
@@ -181,16 +194,18 @@ static int ensure_path_buffers(LupinContext *ctx0, Lane *ctx, uint64_t slots, ui
     if (slots > ctx->capacity)
     {
         PathBuffers &pb = ctx->pb;
-        void **ptrs[] = {(void **)&ctx->hot, (void **)&ctx->shadow, (void **)&ctx->skey, (void **)&pb.vol0, (void **)&pb.vol1, (void **)&pb.queue[0], (void **)&pb.queue[1]};
-        size_t elem[] = {LP_PATH_RECORD_BYTES, LP_PATH_RECORD_BYTES, 4, 16, 16, 4, 4};
+        void **ptrs[] = {(void **)&ctx->hot, (void **)&ctx->shadow, (void **)&ctx->skey, (void **)&pb.vol0, (void **)&pb.vol1, (void **)&pb.queue[0], (void **)&pb.queue[1],
+                         (void **)&pb.retrace};
+        size_t elem[] = {LP_PATH_RECORD_BYTES, LP_PATH_RECORD_BYTES, 4, 16, 16, 4, 4, 8};   // re-trace tokens: up to two jobs per slot (shadow rays)
+        constexpr int NPTRS = 8;
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         // the lane holds nothing until every allocation has succeeded: a failure part-way (hipMalloc returns through
         // HIP_TRY) must not leave a capacity behind that a later, smaller dispatch would trust
         ctx->capacity = 0;
         ctx->pb_generation++;
-        for (int k = 0; k < 7; k++)
+        for (int k = 0; k < NPTRS; k++)
             if (*ptrs[k]) { hipFree(*ptrs[k]); *ptrs[k] = nullptr; }
-        for (int k = 0; k < 7; k++)
+        for (int k = 0; k < NPTRS; k++)
             HIP_TRY(hipMalloc(ptrs[k], (size_t)slots * elem[k]));
         ctx->capacity = slots;
     }
@@ -200,14 +215,238 @@ static int ensure_path_buffers(LupinContext *ctx0, Lane *ctx, uint64_t slots, ui
         ctx->counts_capacity = 0;
         if (ctx->pb.counts) hipFree(ctx->pb.counts);
         ctx->pb.counts = nullptr;
-        ctx->pb.cursors = nullptr;
-        // queue counters, then the persistent tracer's hand-out cursors (two per iteration): one allocation, one clear per call
-        HIP_TRY(hipMalloc((void **)&ctx->pb.counts, 3 * (size_t)(iterations + 2) * LP_SHARDS * sizeof(uint32_t)));
+        ctx->pb.cursors = ctx->pb.retrace_counts = ctx->pb.retrace_cursors = nullptr;
+        // queue counters, then the persistent tracer's hand-out cursors, the re-trace counters and the re-trace cursors (two
+        // per iteration each): one allocation, one clear per call
+        HIP_TRY(hipMalloc((void **)&ctx->pb.counts, LP_COUNTER_ROWS * (size_t)(iterations + 2) * LP_SHARDS * sizeof(uint32_t)));
         ctx->counts_capacity = iterations + 2;
         ctx->pb.cursors = ctx->pb.counts + (size_t)ctx->counts_capacity * LP_SHARDS;
+        ctx->pb.retrace_counts = ctx->pb.cursors + 2 * (size_t)ctx->counts_capacity * LP_SHARDS;
+        ctx->pb.retrace_cursors = ctx->pb.retrace_counts + 2 * (size_t)ctx->counts_capacity * LP_SHARDS;
         ctx->pb_generation++;
     }
     return LUPIN_OK;
+}
+
+// Four-wide collapse of a binary hierarchy given as child-pair nodes (`bin`, references as in WideNode.d): starting from
+// a node's two children, the internal child with the largest box surface is replaced by its own two children until the
+// node has four children or only leaves.  Every child box is a box of the reference's tree, every leaf keeps its
+// reference, so the set of triangles under a reference is unchanged.
+// A child is opened only if BOTH its children's boxes lie inside its own box (exact comparison): then passing a
+// grandchild's slab test implies passing the dropped child's (the slab test is monotone under box inclusion: same
+// roundings of monotone operations), so the wide traversal skips nothing the reference's would not skip.  The
+// reference's builder does produce boxes that are not nested (its child boxes come from centroid BINS, its partition from
+// a comparison with the split plane; a triangle on the wrong side of that rounding is outside its node's stored box --
+// first seen as the one ray in 8 x 10^5 whose closest hit the binary order misses): such a child stays a child.
+// WideNode.d.z carries, per child of a pair (bit 0 left, bit 1 right), "some triangle below is not inside this child's
+// box" (blas_child_pairs); it becomes REF_LEAKY in the wide node's child reference: those children are never pruned by distance.  Nodes are appended to `out` in depth-first order
+// (a 128-byte node is a cache line of its own: order among nodes does not matter to the caches).  Returns the root
+// reference (a leaf root passes through).
+static uint32_t collapse_to_wide4(const std::vector<WideNode> &bin, uint32_t root_ref, std::vector<Wide4> &out, uint32_t *out_depth = nullptr)
+{
+    if (out_depth) *out_depth = 0;
+    if (root_ref & REF_LEAF) return root_ref;
+    struct Child { float lo[3], hi[3]; uint32_t ref; bool leaky, closed; };
+    auto children_of = [&](uint32_t b, Child &l, Child &r) {
+        const WideNode &w = bin[b];
+        l.lo[0] = w.a.x; l.lo[1] = w.a.y; l.lo[2] = w.a.z; l.hi[0] = w.a.w; l.hi[1] = w.b.x; l.hi[2] = w.b.y; l.ref = w.d.x;
+        r.lo[0] = w.b.z; r.lo[1] = w.b.w; r.lo[2] = w.c.x; r.hi[0] = w.c.y; r.hi[1] = w.c.z; r.hi[2] = w.c.w; r.ref = w.d.y;
+        l.leaky = (w.d.z & 1u) != 0; r.leaky = (w.d.z & 2u) != 0;
+        l.closed = r.closed = false;
+    };
+    auto inside = [](const Child &in, const Child &out) {   // exact; a NaN bound is "not inside"
+        for (int ax = 0; ax < 3; ax++)
+            if (!(in.lo[ax] >= out.lo[ax] && in.hi[ax] <= out.hi[ax])) return false;
+        return true;
+    };
+    auto area = [](const Child &c) {
+        const double ex = (double)c.hi[0] - c.lo[0], ey = (double)c.hi[1] - c.lo[1], ez = (double)c.hi[2] - c.lo[2];
+        const double a = ex * ey + ey * ez + ez * ex;
+        return a == a ? a : 0.0;
+    };
+    struct Item { uint32_t bin_node, wide_node, depth; };
+    std::vector<Item> todo;
+    const uint32_t root = (uint32_t)out.size();
+    out.emplace_back();
+    todo.push_back({root_ref, root, 1u});
+    const float nanf_ = std::nanf("");
+    while (!todo.empty())
+    {
+        const Item it = todo.back();
+        todo.pop_back();
+        if (out_depth) *out_depth = std::max(*out_depth, it.depth);
+        Child c[4];
+        int n = 2;
+        children_of(it.bin_node, c[0], c[1]);
+        while (n < 4)
+        {
+            int pick = -1;
+            double best = -1.0;
+            for (int k = 0; k < n; k++)
+                if (!(c[k].ref & REF_LEAF) && !c[k].closed) { const double a = area(c[k]); if (a > best) { best = a; pick = k; } }
+            if (pick < 0) break;
+            Child l, r;
+            children_of(c[pick].ref, l, r);
+            if (!inside(l, c[pick]) || !inside(r, c[pick])) { c[pick].closed = true; continue; }   // not nested: this box must be tested
+            c[pick] = l;
+            c[n++] = r;
+        }
+        Wide4 w;
+        float *lo[3] = {&w.lox.x, &w.loy.x, &w.loz.x}, *hi[3] = {&w.hix.x, &w.hiy.x, &w.hiz.x};
+        uint32_t refs[4];
+        for (int k = 0; k < 4; k++)
+        {
+            for (int ax = 0; ax < 3; ax++) { lo[ax][k] = k < n ? c[k].lo[ax] : nanf_; hi[ax][k] = k < n ? c[k].hi[ax] : nanf_; }
+            refs[k] = REF_NONE;
+            if (k < n)
+            {
+                if (c[k].ref & REF_LEAF) refs[k] = c[k].ref;
+                else
+                {
+                    refs[k] = (uint32_t)out.size();
+                    out.emplace_back();
+                    todo.push_back({c[k].ref, refs[k], it.depth + 1});
+                }
+            }
+        }
+        for (int k = 0; k < n; k++) if (c[k].leaky) refs[k] |= REF_LEAKY;
+        w.ref = make_uint4(refs[0], refs[1], refs[2], refs[3]);
+        w.pad = make_uint4(0u, 0u, 0u, 0u);
+        out[it.wide_node] = w;
+    }
+    return root;
+}
+
+// One mesh's BLAS (the reference's BvhNode array, data_structures.rs:196-325) as child-pair nodes appended to `blas`:
+// node index -> child reference (leaf: REF_LEAF | global index of its first triangle; internal: index into `blas`).
+// `leaf_ends` receives the global index of every leaf's last triangle.  Returns the root reference; *why != nullptr on a
+// malformed array (the caller has checked that the array is a tree).
+// With vertex data (verts_pos4 / indices, mesh-local) the boxes are also checked against what they should bound -- the wide
+// tracer's certificate needs to know where the reference's boxes do not:
+//   WideNode.d.z bit 0 / 1  the left / right child's stored box does not contain every triangle below it
+//   leaky_tris              (global indices) triangles that are not inside every box above them, leaf box included
+static uint32_t blas_child_pairs(const LupinBvhNode *nodes, uint32_t num_nodes, uint32_t ntris, uint32_t tri_offset, std::vector<WideNode> &blas,
+                                 std::vector<uint32_t> &leaf_ends, const char **why,
+                                 const float *verts_pos4 = nullptr, const uint32_t *indices = nullptr, std::vector<uint32_t> *leaky_tris = nullptr)
+{
+    *why = nullptr;
+    std::vector<uint32_t> ref(num_nodes);
+    uint32_t wide_base = (uint32_t)blas.size(), wide_count = 0;
+    for (uint32_t n = 0; n < num_nodes; n++)
+    {
+        const LupinBvhNode &nd = nodes[n];
+        if (nd.tri_count > 0)
+        {
+            if ((uint64_t)nd.tri_begin_or_first_child + nd.tri_count > ntris) { *why = "BLAS leaf range out of bounds"; return 0; }
+            ref[n] = REF_LEAF | (tri_offset + nd.tri_begin_or_first_child);
+            leaf_ends.push_back(tri_offset + nd.tri_begin_or_first_child + nd.tri_count - 1);
+        }
+        else
+        {
+            if ((uint64_t)nd.tri_begin_or_first_child + 1 >= num_nodes) { *why = "BLAS child index out of bounds"; return 0; }
+            ref[n] = wide_base + wide_count++;
+        }
+    }
+    // what the boxes should bound: true bounds per node (bottom-up) and, top-down, the intersection of the boxes above a leaf
+    std::vector<uint8_t> leaky_node(num_nodes, 0);
+    if (verts_pos4 && indices)
+    {
+        struct B { float lo[3], hi[3]; };
+        auto tri_bounds = [&](uint32_t t) {
+            B b;
+            for (int ax = 0; ax < 3; ax++) { b.lo[ax] = INFINITY; b.hi[ax] = -INFINITY; }
+            for (int k = 0; k < 3; k++)
+                for (int ax = 0; ax < 3; ax++)
+                {
+                    const float x = verts_pos4[(size_t)indices[(size_t)t * 3 + k] * 4 + ax];
+                    b.lo[ax] = std::min(b.lo[ax], x); b.hi[ax] = std::max(b.hi[ax], x);
+                }
+            return b;
+        };
+        std::vector<B> truth(num_nodes);
+        // iterative post-order over the tree rooted at node 0 (children may have any index)
+        std::vector<std::pair<uint32_t, int>> st;
+        st.push_back({0u, 0});
+        while (!st.empty())
+        {
+            auto [n, phase] = st.back();
+            const LupinBvhNode &nd = nodes[n];
+            if (nd.tri_count > 0)
+            {
+                B b;
+                for (int ax = 0; ax < 3; ax++) { b.lo[ax] = INFINITY; b.hi[ax] = -INFINITY; }
+                for (uint32_t t = nd.tri_begin_or_first_child; t < nd.tri_begin_or_first_child + nd.tri_count; t++)
+                {
+                    const B tb = tri_bounds(t);
+                    for (int ax = 0; ax < 3; ax++) { b.lo[ax] = std::min(b.lo[ax], tb.lo[ax]); b.hi[ax] = std::max(b.hi[ax], tb.hi[ax]); }
+                }
+                truth[n] = b;
+                st.pop_back();
+            }
+            else if (phase == 0)
+            {
+                st.back().second = 1;
+                st.push_back({nd.tri_begin_or_first_child, 0});
+                st.push_back({nd.tri_begin_or_first_child + 1, 0});
+                continue;
+            }
+            else
+            {
+                const B &l = truth[nd.tri_begin_or_first_child], &r = truth[nd.tri_begin_or_first_child + 1];
+                for (int ax = 0; ax < 3; ax++) { truth[n].lo[ax] = std::min(l.lo[ax], r.lo[ax]); truth[n].hi[ax] = std::max(l.hi[ax], r.hi[ax]); }
+                st.pop_back();
+            }
+            bool in = true;
+            for (int ax = 0; ax < 3; ax++) in = in && truth[n].lo[ax] >= nd.aabb_min[ax] && truth[n].hi[ax] <= nd.aabb_max[ax];
+            leaky_node[n] = in ? 0 : 1;
+        }
+        if (leaky_tris)
+        {
+            // top-down: clip = intersection of the stored boxes from the root down to the node
+            std::vector<std::pair<uint32_t, B>> down;
+            B all;
+            for (int ax = 0; ax < 3; ax++) { all.lo[ax] = -INFINITY; all.hi[ax] = INFINITY; }
+            down.push_back({0u, all});
+            while (!down.empty())
+            {
+                auto [n, clip] = down.back();
+                down.pop_back();
+                const LupinBvhNode &nd = nodes[n];
+                for (int ax = 0; ax < 3; ax++) { clip.lo[ax] = std::max(clip.lo[ax], nd.aabb_min[ax]); clip.hi[ax] = std::min(clip.hi[ax], nd.aabb_max[ax]); }
+                if (nd.tri_count > 0)
+                {
+                    for (uint32_t t = nd.tri_begin_or_first_child; t < nd.tri_begin_or_first_child + nd.tri_count; t++)
+                    {
+                        const B tb = tri_bounds(t);
+                        bool in = true;
+                        for (int ax = 0; ax < 3; ax++) in = in && tb.lo[ax] >= clip.lo[ax] && tb.hi[ax] <= clip.hi[ax];
+                        if (!in) leaky_tris->push_back(tri_offset + t);
+                    }
+                }
+                else
+                {
+                    down.push_back({nd.tri_begin_or_first_child, clip});
+                    down.push_back({nd.tri_begin_or_first_child + 1, clip});
+                }
+            }
+        }
+    }
+    blas.resize(wide_base + wide_count);
+    for (uint32_t n = 0; n < num_nodes; n++)
+    {
+        const LupinBvhNode &nd = nodes[n];
+        if (nd.tri_count > 0) continue;
+        const uint32_t lc = nd.tri_begin_or_first_child, rc = lc + 1;
+        const LupinBvhNode &l = nodes[lc];
+        const LupinBvhNode &r = nodes[rc];
+        WideNode w;
+        w.a = make_float4(l.aabb_min[0], l.aabb_min[1], l.aabb_min[2], l.aabb_max[0]);
+        w.b = make_float4(l.aabb_max[1], l.aabb_max[2], r.aabb_min[0], r.aabb_min[1]);
+        w.c = make_float4(r.aabb_min[2], r.aabb_max[0], r.aabb_max[1], r.aabb_max[2]);
+        w.d = make_uint4(ref[lc], ref[rc], (leaky_node[lc] ? 1u : 0u) | (leaky_node[rc] ? 2u : 0u), 0u);
+        blas[ref[n]] = w;
+    }
+    return ref[0];
 }
 
 // depth of a hierarchy in internal levels = worst-case number of parked far children
@@ -253,6 +492,31 @@ static uint32_t persistent_grid_t(LupinContext *ctx, const LupinScene *scene, si
     }
     return cached;
 }
+// grid of the four-wide instantiation (its own LDS footprint and register count)
+template <int TYPE>
+static uint32_t wide_grid_t(LupinContext *ctx, const LupinScene *scene, size_t lds)
+{
+    uint32_t &cached = const_cast<LupinScene *>(scene)->wide_blocks[TYPE];
+    if (cached == 0)
+    {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extend_persistent<TYPE, false, 0, false, true, false>, LP_BLOCK, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (ctx->blocks_per_cu_override > 0) per_cu = ctx->blocks_per_cu_override;
+        cached = std::max(64u, ctx->num_cus * (uint32_t)per_cu / 64u * 64u);
+    }
+    return cached;
+}
+static uint32_t wide_grid(LupinContext *ctx, const LupinScene *scene, uint32_t type, size_t lds)
+{
+    switch (type)
+    {
+    case LUPIN_PATHTRACE_STANDARD: return wide_grid_t<LUPIN_PATHTRACE_STANDARD>(ctx, scene, lds);
+    case LUPIN_PATHTRACE_MIS: return wide_grid_t<LUPIN_PATHTRACE_MIS>(ctx, scene, lds);
+    case LUPIN_PATHTRACE_NAIVE: return wide_grid_t<LUPIN_PATHTRACE_NAIVE>(ctx, scene, lds);
+    default: return wide_grid_t<LUPIN_PATHTRACE_DIRECT>(ctx, scene, lds);
+    }
+}
+
 static bool use_persistent(const LupinContext *ctx, bool lds_geo) { return ctx->persistent_extend == 1 || (ctx->persistent_extend == 2 && !lds_geo); }
 static uint32_t persistent_grid(LupinContext *ctx, const LupinScene *scene, uint32_t type, bool lds_geo, size_t lds)
 {
@@ -274,24 +538,73 @@ static bool use_light_stage(const LupinContext *ctx, const LupinScene *scene)
     return ctx->light_stage > 0;
 }
 
-template <int TYPE, bool LDSGEO>
-static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *scene, uint32_t blocks, uint32_t pblocks, size_t lds, uint32_t stack_words, uint32_t iter)
+// launch shape of one call's stage kernels
+struct Shape
 {
+    uint32_t blocks = 0;         // one thread per slot, LP_SHARDS-aligned
+    uint32_t pblocks = 0;        // persistent tracer (binary hierarchy); 0 = the one-ray-per-lane k_extend
+    size_t lds = 0;              // traversal stacks (+ staged geometry)
+    uint32_t stack_words = 0;
+    uint32_t wblocks = 0;        // four-wide tracer; 0 = off
+    size_t wlds = 0;
+    uint32_t wstack_words = 0;
+};
+
+// the tracing stage of MODE 0 (closest hits of the integrator loop) or 1 (recorded shadow rays) on the persistent tracer
+template <int TYPE, bool LDSGEO, int MODE>
+static void launch_persistent_tracer(LupinContext *ctx, Lane *ln, const LupinScene *scene, const Shape &sh, uint32_t iter)
+{
+    hipStream_t st = ln->stream;
+    const FrameParams *fp = ln->d_fp;
+    unsigned long long *work = ln->work_counters, *wide = ln->wide_counters;
+    if constexpr (!LDSGEO)
+    {
+        if (sh.wblocks)
+        {
+            // four-wide traversal with the exactness certificate, then the queries it did not certify in the reference's order
+            if (ctx->counting)
+            {
+                hipLaunchKernelGGL((k_extend_persistent<TYPE, false, MODE, true, true, false>), dim3(sh.wblocks), dim3(LP_BLOCK), sh.wlds, st,
+                                   scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, sh.wstack_words, ctx->node_steps, work, wide);
+                hipLaunchKernelGGL((k_extend_persistent<TYPE, false, MODE, true, false, true>), dim3(sh.pblocks), dim3(LP_BLOCK), sh.lds, st,
+                                   scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, sh.stack_words, ctx->node_steps, work, wide);
+            }
+            else
+            {
+                hipLaunchKernelGGL((k_extend_persistent<TYPE, false, MODE, false, true, false>), dim3(sh.wblocks), dim3(LP_BLOCK), sh.wlds, st,
+                                   scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, sh.wstack_words, ctx->node_steps, work, wide);
+                hipLaunchKernelGGL((k_extend_persistent<TYPE, false, MODE, false, false, true>), dim3(sh.pblocks), dim3(LP_BLOCK), sh.lds, st,
+                                   scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, sh.stack_words, ctx->node_steps, work, wide);
+            }
+            return;
+        }
+    }
+    if (ctx->counting)
+        hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, MODE, true>), dim3(sh.pblocks), dim3(LP_BLOCK), sh.lds, st,
+                           scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, sh.stack_words, ctx->node_steps, work, wide);
+    else
+        hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, MODE, false>), dim3(sh.pblocks), dim3(LP_BLOCK), sh.lds, st,
+                           scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, sh.stack_words, ctx->node_steps, work, wide);
+}
+
+template <int TYPE, bool LDSGEO>
+static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *scene, const Shape &sh, uint32_t iter)
+{
+    const uint32_t blocks = sh.blocks, pblocks = sh.pblocks, stack_words = sh.stack_words;
+    const size_t lds = sh.lds;
     hipStream_t st = ln->stream;
     const FrameParams *fp = ln->d_fp;
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     if (ctx->timing) { e0 = get_event(ctx); e1 = get_event(ctx); e2 = get_event(ctx); hipEventRecord(e0, st); }
     const bool persistent = pblocks != 0;
     unsigned long long *work = ln->work_counters;
-    if (persistent)
+    if constexpr (!LDSGEO)
     {
-        if (ctx->counting)
-            hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, 0, true>), dim3(pblocks), dim3(LP_BLOCK), lds, st,
-                               scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words, ctx->node_steps, work);
-        else
-            hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, 0, false>), dim3(pblocks), dim3(LP_BLOCK), lds, st,
-                               scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words, ctx->node_steps, work);
+        if (ctx->verify_wide && scene->has_wide)   // checker only: every query of this iteration, binary vs wide, one ray per lane
+            hipLaunchKernelGGL(k_verify_wide<0>, dim3(blocks), dim3(LP_BLOCK), std::max(lds, (size_t)ctx->wide_stack_pairs * 2u * LP_BLOCK * sizeof(uint32_t)), st,
+                               scene->dev, fp, ln->pb, iter, ctx->wide_stack_pairs, ln->wide_counters + 2);
     }
+    if (persistent) launch_persistent_tracer<TYPE, LDSGEO, 0>(ctx, ln, scene, sh, iter);
     else
     {
         const bool opaque = scene->all_opaque && ctx->specialize_simple;
@@ -354,12 +667,13 @@ static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *sc
         if (persistent && ctx->persistent_shadow)
         {
             // large scenes: the shadow rays go through the phase-scheduled persistent tracer as well, then a light finish pass
-            if (ctx->counting)
-                hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, 1, true>), dim3(pblocks), dim3(LP_BLOCK), lds, st,
-                                   scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words, ctx->node_steps, work);
-            else
-                hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, 1, false>), dim3(pblocks), dim3(LP_BLOCK), lds, st,
-                                   scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, stack_words, ctx->node_steps, work);
+            if constexpr (!LDSGEO)
+            {
+                if (ctx->verify_wide && scene->has_wide)
+                    hipLaunchKernelGGL(k_verify_wide<1>, dim3(blocks), dim3(LP_BLOCK), std::max(lds, (size_t)ctx->wide_stack_pairs * 2u * LP_BLOCK * sizeof(uint32_t)), st,
+                                       scene->dev, fp, ln->pb, iter, ctx->wide_stack_pairs, ln->wide_counters + 2);
+            }
+            launch_persistent_tracer<TYPE, LDSGEO, 1>(ctx, ln, scene, sh, iter);
             hipLaunchKernelGGL((k_shadow<TYPE, LDSGEO, true>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, stack_words);
         }
         else
@@ -381,28 +695,29 @@ static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *sc
 }
 
 template <int TYPE>
-static void launch_iteration(LupinContext *ctx, Lane *ln, const LupinScene *scene, bool lds_geo, uint32_t blocks, uint32_t pblocks, size_t lds, uint32_t stack_words, uint32_t iter)
+static void launch_iteration(LupinContext *ctx, Lane *ln, const LupinScene *scene, bool lds_geo, const Shape &sh, uint32_t iter)
 {
-    if (lds_geo) launch_iteration_t<TYPE, true>(ctx, ln, scene, blocks, pblocks, lds, stack_words, iter);
-    else launch_iteration_t<TYPE, false>(ctx, ln, scene, blocks, pblocks, lds, stack_words, iter);
+    if (lds_geo) launch_iteration_t<TYPE, true>(ctx, ln, scene, sh, iter);
+    else launch_iteration_t<TYPE, false>(ctx, ln, scene, sh, iter);
 }
 
 // the lane-private part of one call: clear the queue counters, first rays, every iteration of the wavefront
 static hipError_t enqueue_wavefront(LupinContext *ctx, Lane *ln, const LupinScene *scene, uint32_t pathtrace_type, bool lds_geo, uint32_t n,
-                                    uint32_t blocks, uint32_t pblocks, size_t lds, uint32_t stack_words, uint32_t iterations)
+                                    const Shape &sh, uint32_t iterations)
 {
+    const uint32_t blocks = sh.blocks;
     hipStream_t st = ln->stream;
-    hipError_t e = hipMemsetAsync(ln->pb.counts, 0, 3 * (size_t)ln->counts_capacity * LP_SHARDS * sizeof(uint32_t), st);
+    hipError_t e = hipMemsetAsync(ln->pb.counts, 0, LP_COUNTER_ROWS * (size_t)ln->counts_capacity * LP_SHARDS * sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_begin, dim3(blocks), dim3(LP_BLOCK), 0, st, (const FrameParams *)ln->d_fp, ln->pb, n);
     for (uint32_t it = 0; it < iterations; it++)
     {
         switch (pathtrace_type)
         {
-        case LUPIN_PATHTRACE_STANDARD: launch_iteration<LUPIN_PATHTRACE_STANDARD>(ctx, ln, scene, lds_geo, blocks, pblocks, lds, stack_words, it); break;
-        case LUPIN_PATHTRACE_MIS: launch_iteration<LUPIN_PATHTRACE_MIS>(ctx, ln, scene, lds_geo, blocks, pblocks, lds, stack_words, it); break;
-        case LUPIN_PATHTRACE_NAIVE: launch_iteration<LUPIN_PATHTRACE_NAIVE>(ctx, ln, scene, lds_geo, blocks, pblocks, lds, stack_words, it); break;
-        default: launch_iteration<LUPIN_PATHTRACE_DIRECT>(ctx, ln, scene, lds_geo, blocks, pblocks, lds, stack_words, it); break;
+        case LUPIN_PATHTRACE_STANDARD: launch_iteration<LUPIN_PATHTRACE_STANDARD>(ctx, ln, scene, lds_geo, sh, it); break;
+        case LUPIN_PATHTRACE_MIS: launch_iteration<LUPIN_PATHTRACE_MIS>(ctx, ln, scene, lds_geo, sh, it); break;
+        case LUPIN_PATHTRACE_NAIVE: launch_iteration<LUPIN_PATHTRACE_NAIVE>(ctx, ln, scene, lds_geo, sh, it); break;
+        default: launch_iteration<LUPIN_PATHTRACE_DIRECT>(ctx, ln, scene, lds_geo, sh, it); break;
         }
     }
     return hipSuccess;
@@ -505,6 +820,8 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
         if (e == hipSuccess) e = hipMemsetAsync(ln.stat_counters, 0, 2 * LP_SHARDS * sizeof(unsigned long long), ln.stream);
         if (e == hipSuccess) e = hipMalloc((void **)&ln.work_counters, LP_WORK_WORDS * sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMemsetAsync(ln.work_counters, 0, LP_WORK_WORDS * sizeof(unsigned long long), ln.stream);
+        if (e == hipSuccess) e = hipMalloc((void **)&ln.wide_counters, LP_WIDE_WORDS * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMemsetAsync(ln.wide_counters, 0, LP_WIDE_WORDS * sizeof(unsigned long long), ln.stream);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->marker, hipEventDisableTiming);
     if (e != hipSuccess)
@@ -546,6 +863,9 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
     if (shd && strcmp(shd, "simple") == 0) ctx->persistent_shadow = false;
     const char *ns = getenv("LUPIN_NODE_STEPS");
     if (ns) ctx->node_steps = (uint32_t)std::min(16, std::max(1, atoi(ns)));
+    if (const char *tv = getenv("LUPIN_TRAVERSAL")) ctx->wide_traversal = strcmp(tv, "binary") != 0;
+    if (const char *ws = getenv("LUPIN_WIDE_STACK")) ctx->wide_stack_pairs = (uint32_t)std::min(64, std::max(4, atoi(ws)));
+    if (const char *vw = getenv("LUPIN_VERIFY_WIDE")) ctx->verify_wide = atoi(vw) != 0;
     const char *rm = getenv("LUPIN_REFILL_MIN");
     if (rm) ctx->refill_min = (uint32_t)std::min(64, std::max(1, atoi(rm)));
     *out_ctx = ctx;
@@ -565,7 +885,7 @@ void lupin_hip_destroy_context(LupinContext *ctx)
     {
         PathBuffers &pb = ctx->lanes[k].pb;
         void *ptrs[] = {ctx->lanes[k].hot, ctx->lanes[k].shadow, ctx->lanes[k].skey, pb.vol0, pb.vol1, pb.queue[0], pb.queue[1], pb.counts, ctx->lanes[k].stat_counters,
-                        ctx->lanes[k].work_counters};
+                        ctx->lanes[k].work_counters, ctx->lanes[k].wide_counters, pb.retrace};
         for (void *p : ptrs) if (p) hipFree(p);
         if (ctx->lanes[k].done) hipEventDestroy(ctx->lanes[k].done);
         if (ctx->lanes[k].graph_exec) hipGraphExecDestroy(ctx->lanes[k].graph_exec);
@@ -595,6 +915,14 @@ int lupin_hip_set_f16_store_rounding(LupinContext *ctx, int mode)
     CTX_ALIVE_TRY(ctx);
     if (!ctx || (mode != 0 && mode != 1)) return fail(LUPIN_ERR_INVALID_ARGUMENT, "mode must be 0 (toward zero) or 1 (nearest even)");
     ctx->store_rounding = mode;
+    return LUPIN_OK;
+}
+
+int lupin_hip_set_traversal(LupinContext *ctx, int mode)
+{
+    CTX_ALIVE_TRY(ctx);
+    if (!ctx || (mode != LUPIN_TRAVERSAL_WIDE && mode != LUPIN_TRAVERSAL_BINARY)) return fail(LUPIN_ERR_INVALID_ARGUMENT, "unknown traversal mode");
+    ctx->wide_traversal = mode == LUPIN_TRAVERSAL_WIDE;
     return LUPIN_OK;
 }
 
@@ -764,43 +1092,21 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
             tri_indices.push_back(0); tri_indices.push_back(0); tri_indices.push_back(0);
             continue;
         }
-        // node index -> child reference
-        std::vector<uint32_t> ref(m.num_bvh_nodes);
-        uint32_t wide_base = (uint32_t)blas.size(), wide_count = 0;
         for (uint32_t n = 0; n < m.num_bvh_nodes; n++)
-        {
-            const LupinBvhNode &nd = m.bvh_nodes[n];
-            if (nd.tri_count > 0)
-            {
-                if ((uint64_t)nd.tri_begin_or_first_child + nd.tri_count > ntris) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "BLAS leaf range out of bounds"); }
-                ref[n] = REF_LEAF | (md.tri_offset + nd.tri_begin_or_first_child);
-                uint32_t last = md.tri_offset + nd.tri_begin_or_first_child + nd.tri_count - 1;
-                tris[last].v0.w = host_u2f(LEAF_END_BITS);
-            }
-            else
-            {
-                if ((uint64_t)nd.tri_begin_or_first_child + 1 >= m.num_bvh_nodes) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "BLAS child index out of bounds"); }
-                ref[n] = wide_base + wide_count++;
-            }
-        }
-        blas.resize(wide_base + wide_count);
-        for (uint32_t n = 0; n < m.num_bvh_nodes; n++)
-        {
-            const LupinBvhNode &nd = m.bvh_nodes[n];
-            if (nd.tri_count > 0) continue;
-            const LupinBvhNode &l = m.bvh_nodes[nd.tri_begin_or_first_child];
-            const LupinBvhNode &r = m.bvh_nodes[nd.tri_begin_or_first_child + 1];
-            WideNode w;
-            w.a = make_float4(l.aabb_min[0], l.aabb_min[1], l.aabb_min[2], l.aabb_max[0]);
-            w.b = make_float4(l.aabb_max[1], l.aabb_max[2], r.aabb_min[0], r.aabb_min[1]);
-            w.c = make_float4(r.aabb_min[2], r.aabb_max[0], r.aabb_max[1], r.aabb_max[2]);
-            w.d = make_uint4(ref[nd.tri_begin_or_first_child], ref[nd.tri_begin_or_first_child + 1], 0u, 0u);
-            blas[ref[n]] = w;
-        }
-        mesh_root[mi] = ref[0];
+            if (m.bvh_nodes[n].tri_count == 0 && (uint64_t)m.bvh_nodes[n].tri_begin_or_first_child + 1 >= m.num_bvh_nodes)
+            { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "BLAS child index out of bounds"); }
         const uint32_t bd = blas_depth(m.bvh_nodes, m.num_bvh_nodes);
         if (bd == 0xFFFFFFFFu) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "BLAS is not a tree"); }
         max_blas_depth = std::max(max_blas_depth, bd);
+        std::vector<uint32_t> leaf_ends, leaky_tris;
+        const char *why = nullptr;
+        const uint32_t root_ref = blas_child_pairs(m.bvh_nodes, m.num_bvh_nodes, ntris, md.tri_offset, blas, leaf_ends, &why, m.verts_pos, m.indices, &leaky_tris);
+        if (why) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, why); }
+        // v0.w of a triangle: bit 0 = last of its leaf, bit 1 = not inside every box above it (the wide tracer re-traces hits on it)
+        for (uint32_t t : leaky_tris) tris[t].v0.w = host_u2f(TRI_LEAKY_BITS);
+        for (uint32_t last : leaf_ends) tris[last].v0.w = host_u2f(__builtin_bit_cast(uint32_t, tris[last].v0.w) | LEAF_END_BITS);
+        sc->leaky_triangles += leaky_tris.size();
+        mesh_root[mi] = root_ref;
     }
 
     // ---- TLAS ----
@@ -859,6 +1165,20 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
     }
     sc->stack_entries = tlas_depth + max_blas_depth + 1;
 
+    // ---- the same hierarchies four-wide (wide tracer; scenes small enough for LDS staging are traced by k_extend) ----
+    std::vector<Wide4> wide4;   // TLAS nodes first, then every mesh's BLAS nodes: one array, global indices
+    std::vector<uint32_t> mesh_root4(s.num_meshes, REF_LEAF);
+    uint32_t tlas4_root = tlas_root;
+    const size_t lds_bytes_if_staged = tlas.size() * 80 + blas.size() * 80 + tris.size() * 48 + (size_t)s.num_instances * 80;
+    const bool build_wide = s.num_instances > 0 && !(lds_bytes_if_staged <= LP_GEO_LDS_LIMIT && ctx->lds_geometry);
+    if (build_wide)
+    {
+        tlas4_root = collapse_to_wide4(tlas, tlas_root, wide4);
+        for (uint32_t mi = 0; mi < s.num_meshes; mi++) mesh_root4[mi] = collapse_to_wide4(blas, mesh_root[mi], wide4);
+        if (wide4.size() >= (size_t)REF_INDEX_MASK || tris.size() >= (size_t)REF_INDEX_MASK) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "scene too large for 30-bit references"); }
+        sc->has_wide = true;
+    }
+
     // ---- instances ----
     std::vector<InstanceDev> instances(s.num_instances);
     uint32_t mat_types_seen = 0;
@@ -886,6 +1206,9 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
         mat_types_seen |= 1u << (mat.mat_type & 0xFu);
         instances[i] = d;
     }
+
+    std::vector<uint32_t> inst_root4(s.num_instances);
+    for (uint32_t i = 0; i < s.num_instances; i++) inst_root4[i] = mesh_root4[s.instances[i].mesh_idx];
 
     // ---- textures ----
     std::vector<TextureDev> textures(s.num_textures);
@@ -1003,12 +1326,14 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
         (rc = upload(sc, envs, &dv.environments)) || (rc = upload(sc, lights, &dv.lights)) ||
         (rc = upload(sc, alias_ranges, &dv.alias_ranges)) || (rc = upload(sc, env_alias_ranges, &dv.env_alias_ranges)) ||
         (rc = upload(sc, alias_bins, &dv.alias_bins)) || (rc = upload(sc, geo_blob, &dv.geo_blob)) ||
-        (rc = upload(sc, light_bounds, &dv.light_bounds)))
+        (rc = upload(sc, light_bounds, &dv.light_bounds)) ||
+        (rc = upload(sc, wide4, &dv.wide4)) || (rc = upload(sc, inst_root4, &dv.inst_root4)))
     {
         lupin_hip_scene_destroy(sc);
         return rc;
     }
     dv.tlas_root = tlas_root;
+    dv.tlas4_root = tlas4_root;
     dv.num_lights = s.num_lights;
     dv.num_envs = s.num_environments;
     dv.num_instances = s.num_instances;
@@ -1308,8 +1633,19 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
     if (ctx->timing) { t0 = get_event(ctx); t1 = get_event(ctx); hipEventRecord(t0, st); }
 
     const uint32_t pblocks = persistent_grid(ctx, scene, pathtrace_type, lds_geo, lds);
+    Shape sh;
+    sh.blocks = blocks; sh.pblocks = pblocks; sh.lds = lds; sh.stack_words = stack_words;
+    if (pblocks && !lds_geo && scene->has_wide && ctx->wide_traversal)
+    {
+        // the wide tracer keeps (reference, distance) pairs on a bounded stack; a query that would overflow it is re-traced
+        sh.wstack_words = 2u * ctx->wide_stack_pairs * LP_BLOCK;
+        sh.wlds = (size_t)sh.wstack_words * sizeof(uint32_t);
+        sh.wblocks = wide_grid(ctx, scene, pathtrace_type, sh.wlds);
+    }
+    ctx->last_lanes = lanes;
+    ctx->last_wide = sh.wblocks != 0;
     hipLaunchKernelGGL(k_set_params, dim3(1), dim3(1), 0, st, fp, ln->d_fp);
-    if (ctx->use_graph && !ctx->timing && !ctx->counting)
+    if (ctx->use_graph && !ctx->timing && !ctx->counting && !ctx->verify_wide)
     {
         // Everything between k_set_params and the resolve depends on the call only through *d_fp, so it is captured once per
         // (scene, dispatch size, integrator, buffers) and replayed: one graph launch instead of 2-4 launches per iteration.
@@ -1318,13 +1654,14 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
         key.iterations = iterations; key.stack_words = stack_words; key.lds = (uint32_t)lds; key.pblocks = pblocks;
         key.refill_min = ctx->refill_min; key.node_steps = ctx->node_steps; key.persistent = ctx->persistent_extend;
         key.persistent_shadow = ctx->persistent_shadow ? 1 : 0; key.lds_geometry = lds_geo ? 1 : 0;
+        key.wide_blocks = sh.wblocks; key.wide_stack_words = sh.wstack_words;
         const bool have = ln->graph_exec && key == ln->graph_key;
         if (!have && ln->graph_exec && !(key == ln->seen_key))
         {
             // the lane holds a graph of another shape and this one is new (shapes alternate, e.g. edge tiles): capturing
             // costs about a millisecond, so launch directly and re-capture only if the shape repeats
             ln->seen_key = key;
-            HIP_TRY(enqueue_wavefront(ctx, ln, scene, pathtrace_type, lds_geo, n, blocks, pblocks, lds, stack_words, iterations));
+            HIP_TRY(enqueue_wavefront(ctx, ln, scene, pathtrace_type, lds_geo, n, sh, iterations));
         }
         else
         {
@@ -1333,7 +1670,7 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
                 if (ln->graph_exec) { hipGraphExecDestroy(ln->graph_exec); ln->graph_exec = nullptr; }
                 if (ln->graph) { hipGraphDestroy(ln->graph); ln->graph = nullptr; }
                 HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-                hipError_t ce = enqueue_wavefront(ctx, ln, scene, pathtrace_type, lds_geo, n, blocks, pblocks, lds, stack_words, iterations);
+                hipError_t ce = enqueue_wavefront(ctx, ln, scene, pathtrace_type, lds_geo, n, sh, iterations);
                 hipError_t ee = hipStreamEndCapture(st, &ln->graph);
                 if (ce != hipSuccess || ee != hipSuccess) return fail(LUPIN_ERR_HIP, std::string("graph capture: ") + hipGetErrorString(ce != hipSuccess ? ce : ee));
                 HIP_TRY(hipGraphInstantiate(&ln->graph_exec, ln->graph, nullptr, nullptr, 0));
@@ -1345,7 +1682,7 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
         }
     }
     else
-        HIP_TRY(enqueue_wavefront(ctx, ln, scene, pathtrace_type, lds_geo, n, blocks, pblocks, lds, stack_words, iterations));
+        HIP_TRY(enqueue_wavefront(ctx, ln, scene, pathtrace_type, lds_geo, n, sh, iterations));
     // The frames meet here: the resolve reads prev_frame and overwrites render_target, so it is ordered after everything
     // enqueued so far on the other lane (the previous call's resolve) and, for lane 1, on the primary stream (texture
     // uploads / copies).  The path state itself is private to the lane.
@@ -1424,7 +1761,10 @@ int lupin_hip_stats_reset(LupinContext *ctx, int enable_kernel_timing)
     for (auto &p : ctx->ev_total) { ctx->ev_pool.push_back(p.first); ctx->ev_pool.push_back(p.second); }
     ctx->ev_total.clear();
     for (int k = 0; k < ctx->num_lanes; k++)
+    {
         HIP_TRY(hipMemsetAsync(ctx->lanes[k].work_counters, 0, LP_WORK_WORDS * sizeof(unsigned long long), ctx->lanes[k].stream));
+        HIP_TRY(hipMemsetAsync(ctx->lanes[k].wide_counters, 0, LP_WIDE_WORDS * sizeof(unsigned long long), ctx->lanes[k].stream));
+    }
     ctx->timing = enable_kernel_timing == LUPIN_STATS_KERNEL_TIMING;
     ctx->counting = enable_kernel_timing == LUPIN_STATS_WORK_COUNTERS;
     ctx->extend_launches = 0;
@@ -1448,8 +1788,21 @@ int lupin_hip_stats_get(LupinContext *ctx, LupinStats *out)
     {
         unsigned long long w[LP_WORK_WORDS];
         HIP_TRY(hipMemcpy(w, ctx->lanes[l].work_counters, sizeof(w), hipMemcpyDeviceToHost));
-        for (int m = 0; m < 3; m++) { out->node_visits[m] += w[3 * m + 0]; out->tri_tests[m] += w[3 * m + 1]; out->instance_entries[m] += w[3 * m + 2]; }
+        for (int m = 0; m < 3; m++)
+        {
+            out->node_visits[m] += w[4 * m + 0]; out->tri_tests[m] += w[4 * m + 1]; out->instance_entries[m] += w[4 * m + 2];
+            out->wide_node_visits[m] += w[4 * m + 3];
+        }
+        for (int k = 0; k < 10; k++) out->tracer_rounds[k] += w[12 + k];
+        for (int k = 0; k < 6; k++) out->tracer_cycles[k] += w[22 + k];
+        unsigned long long wd[LP_WIDE_WORDS];
+        HIP_TRY(hipMemcpy(wd, ctx->lanes[l].wide_counters, sizeof(wd), hipMemcpyDeviceToHost));
+        out->wide_queries += wd[0]; out->wide_retraced += wd[1];
+        out->verify_checked += wd[2]; out->verify_flagged += wd[3]; out->verify_mismatches += wd[4]; out->verify_raw_mismatches += wd[5];
+        for (int k = 0; k < 4; k++) out->verify_reasons[k] += wd[6 + k];
     }
+    out->frames_in_flight = (uint32_t)std::max(0, ctx->last_lanes);
+    out->wide_traversal = ctx->last_wide ? 1u : 0u;
     out->extend_launches = ctx->extend_launches;
     auto sum = [](const std::vector<std::pair<hipEvent_t, hipEvent_t>> &v) {
         double ms = 0.0;
@@ -1521,15 +1874,47 @@ int lupin_hip_runtime_info(LupinRuntimeInfo *out)
     return LUPIN_OK;
 }
 
-int lupin_hip_trace_rays(LupinContext *ctx, const LupinScene *scene, uint32_t n, const float *ori_xyz, const float *dir_xyz,
-                         float ray_epsilon, uint32_t *out_hit, float *out_dst, float *out_uv, uint32_t *out_instance, uint32_t *out_tri)
+int64_t lupin_hip_collapse_bvh4(const LupinBvhNode *nodes, uint32_t num_nodes, const float *verts_pos4, uint32_t num_verts, const uint32_t *indices,
+                                uint32_t num_indices, void *out_nodes, uint64_t capacity, uint32_t *out_root, uint8_t *out_tri_flags)
+{
+    if (!nodes || num_nodes == 0 || !out_root) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
+    const uint32_t num_tris = num_indices / 3;
+    for (uint32_t n = 0; n < num_nodes; n++)
+        if (nodes[n].tri_count == 0 && (uint64_t)nodes[n].tri_begin_or_first_child + 1 >= num_nodes) return fail(LUPIN_ERR_INVALID_ARGUMENT, "BLAS child index out of bounds");
+    if (blas_depth(nodes, num_nodes) == 0xFFFFFFFFu) return fail(LUPIN_ERR_INVALID_ARGUMENT, "BLAS is not a tree");
+    if (verts_pos4 && indices)
+        for (uint32_t i = 0; i < num_tris * 3; i++) if (indices[i] >= num_verts) return fail(LUPIN_ERR_INVALID_ARGUMENT, "vertex index out of range");
+    std::vector<WideNode> pairs;
+    std::vector<uint32_t> leaf_ends, leaky;
+    const char *why = nullptr;
+    const uint32_t root = blas_child_pairs(nodes, num_nodes, num_tris, 0u, pairs, leaf_ends, &why, verts_pos4, indices, &leaky);
+    if (why) return fail(LUPIN_ERR_INVALID_ARGUMENT, why);
+    std::vector<Wide4> wide;
+    *out_root = collapse_to_wide4(pairs, root, wide);
+    if (out_tri_flags)
+    {
+        memset(out_tri_flags, 0, num_tris);
+        for (uint32_t t : leaky) out_tri_flags[t] |= 2u;
+        for (uint32_t t : leaf_ends) out_tri_flags[t] |= 1u;
+    }
+    if (out_nodes)
+    {
+        if (wide.size() > capacity) return fail(LUPIN_ERR_INVALID_ARGUMENT, "out_nodes too small");
+        if (!wide.empty()) memcpy(out_nodes, wide.data(), wide.size() * sizeof(Wide4));
+    }
+    return (int64_t)wide.size();
+}
+
+static int trace_rays_impl(LupinContext *ctx, const LupinScene *scene, uint32_t n, const float *ori_xyz, const float *dir_xyz,
+                           float ray_epsilon, uint32_t *out_hit, float *out_dst, float *out_uv, uint32_t *out_instance, uint32_t *out_tri, uint32_t *out_flag)
 {
     CTX_ALIVE_TRY(ctx);
     if (!ctx || !scene || !ori_xyz || !dir_xyz || !out_hit || !out_dst || !out_uv || !out_instance || !out_tri) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
+    if (out_flag && !scene->has_wide) return fail(LUPIN_ERR_INVALID_ARGUMENT, "this scene has no four-wide hierarchy (it is small enough to be staged in LDS)");
     if (n == 0) return LUPIN_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     float *d_ori = nullptr, *d_dir = nullptr, *d_dst = nullptr, *d_uv = nullptr;
-    uint32_t *d_hit = nullptr, *d_inst = nullptr, *d_tri = nullptr;
+    uint32_t *d_hit = nullptr, *d_inst = nullptr, *d_tri = nullptr, *d_flag = nullptr;
     HIP_TRY(hipMalloc((void **)&d_ori, (size_t)n * 12));
     HIP_TRY(hipMalloc((void **)&d_dir, (size_t)n * 12));
     HIP_TRY(hipMalloc((void **)&d_dst, (size_t)n * 4));
@@ -1537,11 +1922,22 @@ int lupin_hip_trace_rays(LupinContext *ctx, const LupinScene *scene, uint32_t n,
     HIP_TRY(hipMalloc((void **)&d_hit, (size_t)n * 4));
     HIP_TRY(hipMalloc((void **)&d_inst, (size_t)n * 4));
     HIP_TRY(hipMalloc((void **)&d_tri, (size_t)n * 4));
+    if (out_flag) HIP_TRY(hipMalloc((void **)&d_flag, (size_t)n * 4));
     HIP_TRY(hipMemcpyAsync(d_ori, ori_xyz, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(d_dir, dir_xyz, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
-    size_t lds = (size_t)scene->stack_entries * LP_BLOCK * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_trace, dim3((n + LP_BLOCK - 1) / LP_BLOCK), dim3(LP_BLOCK), lds, ctx->stream, scene->dev, n, d_ori, d_dir, ray_epsilon,
-                       d_hit, d_dst, d_uv, d_inst, d_tri);
+    if (out_flag)
+    {
+        const size_t lds = (size_t)ctx->wide_stack_pairs * 2u * LP_BLOCK * sizeof(uint32_t);
+        hipLaunchKernelGGL(k_trace_wide, dim3((n + LP_BLOCK - 1) / LP_BLOCK), dim3(LP_BLOCK), lds, ctx->stream, scene->dev, n, d_ori, d_dir, ray_epsilon,
+                           ctx->wide_stack_pairs, d_hit, d_dst, d_uv, d_inst, d_tri, d_flag);
+        HIP_TRY(hipMemcpyAsync(out_flag, d_flag, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    else
+    {
+        const size_t lds = (size_t)scene->stack_entries * LP_BLOCK * sizeof(uint32_t);
+        hipLaunchKernelGGL(k_trace, dim3((n + LP_BLOCK - 1) / LP_BLOCK), dim3(LP_BLOCK), lds, ctx->stream, scene->dev, n, d_ori, d_dir, ray_epsilon,
+                           d_hit, d_dst, d_uv, d_inst, d_tri);
+    }
     HIP_TRY(hipMemcpyAsync(out_hit, d_hit, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(out_dst, d_dst, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(out_uv, d_uv, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1549,7 +1945,22 @@ int lupin_hip_trace_rays(LupinContext *ctx, const LupinScene *scene, uint32_t n,
     HIP_TRY(hipMemcpyAsync(out_tri, d_tri, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     hipFree(d_ori); hipFree(d_dir); hipFree(d_dst); hipFree(d_uv); hipFree(d_hit); hipFree(d_inst); hipFree(d_tri);
+    if (d_flag) hipFree(d_flag);
     return LUPIN_OK;
+}
+
+int lupin_hip_trace_rays(LupinContext *ctx, const LupinScene *scene, uint32_t n, const float *ori_xyz, const float *dir_xyz,
+                         float ray_epsilon, uint32_t *out_hit, float *out_dst, float *out_uv, uint32_t *out_instance, uint32_t *out_tri)
+{
+    return trace_rays_impl(ctx, scene, n, ori_xyz, dir_xyz, ray_epsilon, out_hit, out_dst, out_uv, out_instance, out_tri, nullptr);
+}
+
+int lupin_hip_trace_rays_wide(LupinContext *ctx, const LupinScene *scene, uint32_t n, const float *ori_xyz, const float *dir_xyz,
+                              float ray_epsilon, uint32_t *out_hit, float *out_dst, float *out_uv, uint32_t *out_instance, uint32_t *out_tri,
+                              uint32_t *out_needs_retrace)
+{
+    if (!out_needs_retrace) return fail(LUPIN_ERR_INVALID_ARGUMENT, "null argument");
+    return trace_rays_impl(ctx, scene, n, ori_xyz, dir_xyz, ray_epsilon, out_hit, out_dst, out_uv, out_instance, out_tri, out_needs_retrace);
 }
 
 int lupin_hip_detmath_probe(LupinContext *ctx, int fn, uint32_t n, const float *x, const float *y, float *out)

@@ -83,6 +83,11 @@ struct PathBuffers
     uint32_t *counts;     // counts[k * LP_SHARDS + s] = live paths of shard s entering iteration k
     PathField<uint32_t> skey;     // Standard integrator on the persistent tracer: k_sort_queue's key of the path's hit, written by the tracer (always a plane)
     uint32_t *cursors;    // cursors[(2 k + mode) * LP_SHARDS + s]: how much of shard s the persistent tracer's waves have taken in iteration k
+    // Wide tracer: queries it could not certify (lupin_device.hpp "Wide traversal") are appended here, per shard, as job
+    // tokens (MODE 0: slot; MODE 1: 2 * slot + ray) and re-traced by the binary tracer in the reference's order.
+    uint32_t *retrace;          // [shard * 2 * shard_cap + i]
+    uint32_t *retrace_counts;   // [(2 k + mode) * LP_SHARDS + s]
+    uint32_t *retrace_cursors;  // hand-out cursors of the re-trace launch, same indexing
     // Light-pdf stage (k_light_pdf, Standard): k_shade does not append; it tags its queue entry with what became of the
     // path (QUEUE_STATE_*), parks numerator and BSDF pdf of a waiting vertex in sh_f0, and k_light_pdf finishes the
     // iteration and appends the survivors in the queue's order.
@@ -292,12 +297,15 @@ __device__ __forceinline__ void trace_alpha(const Geo &geo, const SceneDev &sc, 
 }
 
 // Work counters (bench.py's roofline numerator, lupin_hip_stats_reset(ctx, 2)): the COUNT instantiations of the tracing
-// kernels wrap their geometry accessor in GeoTally and add the wave's totals to work[3 * mode + {0 nodes, 1 triangles, 2 instances}].
-// All 64 lanes must be active when this is called.
-__device__ __forceinline__ void tally_flush(const uint32_t (&tally)[3], unsigned long long *work)
+// kernels wrap their geometry accessor in GeoTally and add the wave's totals to work[4 * mode + {0 nodes, 1 triangles, 2 instances,
+// 3 four-wide nodes}].  All 64 lanes must be active when this is called.
+constexpr int LP_TALLY = 4;
+constexpr int LP_ROUND_BASE = 12, LP_ROUND_WORDS = 10;   // work[12 .. 21]: round statistics of the persistent tracer (closest-hit mode)
+constexpr int LP_CLOCK_BASE = 22, LP_CLOCK_WORDS = 6;    // work[22 .. 27]: shader-clock cycles per wave spent in refill | N | T | I | F rounds, and in the whole loop
+__device__ __forceinline__ void tally_flush(const uint32_t (&tally)[LP_TALLY], unsigned long long *work)
 {
     #pragma unroll
-    for (int k = 0; k < 3; k++)
+    for (int k = 0; k < LP_TALLY; k++)
     {
         uint32_t v = tally[k];
         #pragma unroll
@@ -321,7 +329,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launc
     const FrameParams fp = *fpp;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     const auto base_geo = make_geo<LDSGEO>(sc, lds_stack, stack_words);
-    uint32_t tally[3] = {0u, 0u, 0u};
+    uint32_t tally[LP_TALLY] = {0u, 0u, 0u, 0u};
     const auto geo = with_tally<COUNT>(base_geo, tally);
     const uint32_t shard = blockIdx.x % LP_SHARDS;
     const uint32_t count = pb.counts[iter * LP_SHARDS + shard];
@@ -385,38 +393,58 @@ __device__ __forceinline__ uint32_t shade_sort_key(bool in_medium, bool miss, ui
 // MODE 1: the shadow rays k_shade recorded for MIS / Direct (two jobs per queue entry, plain closest hit); their hits go
 //         to next_hit / next_tri (MIS ray 0, which doubles as the next vertex) or sh_hit1 / sh_f1.w, and
 //         k_shadow<.., PRETRACED> folds them into the radiance.
-template <int TYPE, bool LDSGEO, int MODE, bool COUNT>
+// WIDE:   the four-wide hierarchies with the exactness certificate (lupin_device.hpp "Wide traversal"): a query whose
+//         result is not certified writes nothing and leaves its job token in pb.retrace.
+// RETRACE: serves those tokens (a second launch of the binary instantiation): the reference's order, by construction.
+// wide_stats (one writer per launch): [0] queries the wide tracer took, [1] queries it handed to the re-trace.
+template <int TYPE, bool LDSGEO, int MODE, bool COUNT, bool WIDE = false, bool RETRACE = false>
 __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, const FrameParams *__restrict__ fpp, PathBuffers pb, uint32_t iter,
                                                                 unsigned long long *shard_stats, uint32_t refill_min, uint32_t stack_words, uint32_t nsteps,
-                                                                unsigned long long *work)
+                                                                unsigned long long *work, unsigned long long *wide_stats)
 {
+    static_assert(!(WIDE && (LDSGEO || RETRACE)), "the wide hierarchies are traversed from global memory; the re-trace is binary");
     const FrameParams fp = *fpp;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     const auto base_geo = make_geo<LDSGEO>(sc, lds_stack, stack_words);
-    uint32_t tally[3] = {0u, 0u, 0u};
+    uint32_t tally[LP_TALLY] = {0u, 0u, 0u, 0u};
     const auto geo = with_tally<COUNT>(base_geo, tally);
     static_assert(LP_SHARDS <= LP_BLOCK && 256 % LP_SHARDS == 0, "block 0 books one shard per thread; 64-block grids hold whole waves per shard");
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t *counts = pb.counts + (size_t)iter * LP_SHARDS;
-    const uint32_t *queue = pb.queue[iter & 1];
-    if (MODE == 0 && blockIdx.x == 0 && tid < LP_SHARDS) { const uint32_t c = counts[tid]; if (c) shard_stats[tid * 2 + 0] += c; }   // one writer per shard per launch
+    const size_t mode_row = ((size_t)iter * 2u + (MODE == 1 ? 1u : 0u)) * LP_SHARDS;
+    const uint32_t *counts = RETRACE ? pb.retrace_counts + mode_row : pb.counts + (size_t)iter * LP_SHARDS;
+    if (!RETRACE && MODE == 0 && blockIdx.x == 0 && tid < LP_SHARDS) { const uint32_t c = counts[tid]; if (c) shard_stats[tid * 2 + 0] += c; }   // one writer per shard per launch
+    if ((WIDE || RETRACE) && blockIdx.x == 0 && tid < 64u)
+    {
+        // the first wave books the launch's job count (no LDS: a static allocation here would cost the 40 KB stack its
+        // fourth block per CU)
+        uint32_t c = 0;
+        for (uint32_t k = lane; k < LP_SHARDS; k += 64u) c += counts[k] * ((MODE == 1 && !RETRACE) ? 2u : 1u);
+        #pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+        if (lane == 0 && c) wide_stats[RETRACE ? 1 : 0] += c;   // one writer per launch
+    }
 
     // The grid holds `wps` waves per shard; the waves of a shard hand its queue out among themselves, one atomic per
     // refill (a static share per wave leaves the launch waiting for the wave whose few hundred rays happened to be the
     // deep ones: with 1 M rays per launch -- an eighth of the 4K frame -- the tracer ran at half its large-launch rate).
     const uint32_t wave = blockIdx.x * (LP_BLOCK / 64) + tid / 64;         // wave-uniform
     const uint32_t shard = wave % LP_SHARDS;
-    const uint32_t cnt = counts[shard] * (MODE == 1 ? 2u : 1u);   // jobs
+    const uint32_t cnt = counts[shard] * ((MODE == 1 && !RETRACE) ? 2u : 1u);   // jobs (a re-trace token is one job)
     if (cnt == 0) return;
-    uint32_t *cursor = pb.cursors + ((size_t)iter * 2u + (MODE == 1 ? 1u : 0u)) * LP_SHARDS + shard;
+    uint32_t *cursor = (RETRACE ? pb.retrace_cursors : pb.cursors) + mode_row + shard;
     const size_t shard_base = (size_t)shard * pb.shard_cap;
+    const uint32_t *queue = RETRACE ? pb.retrace + 2u * shard_base : pb.queue[iter & 1] + shard_base;
     bool exhausted = false;                                                 // wave-uniform: the shard's queue is handed out
 
     const float eps = fp.pc.ray_epsilon;
+    const float abs_margin = 0.25f * eps;                                   // wide_threshold's absolute part
     constexpr uint32_t REF_DONE = 0xFFFFFFFFu;
+    constexpr uint32_t REF_SKIP = 0x3FFFFFFFu;                              // WIDE: "pop again" -- an internal-node reference no scene can hold (index 2^30 - 1)
+    const uint32_t stack_entries = stack_words / LP_BLOCK;                  // WIDE: (reference, distance) pairs -> stack_entries / 2 of them
 
     // per-lane ray + traversal state
     bool active = false;
+    bool flagged = false;     // WIDE: this query goes to the re-trace
     uint32_t slot = 0, rng = 0, rng_in = 0, alpha_k = 0, ray_k = 0;
     bool in_medium = false;   // META_VOLUME of the path (k_sort_queue's key)
     float total_dst = 0.0f;
@@ -430,15 +458,37 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
         inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         co = o; cd = d; cinv = inv_d;
         sp = 0; blas_base = 0xFFFFFFFFu;
-        cur = sc.num_instances ? sc.tlas_root : REF_DONE;
+        cur = sc.num_instances ? (WIDE ? sc.tlas4_root : sc.tlas_root) : REF_DONE;
         best.t = LP_F32_MAX; best.u = 0.0f; best.v = 0.0f; best.tri = 0u; best.inst = HIT_MISS;
     };
     auto pop = [&]() {
-        if (sp == blas_base) { blas_base = 0xFFFFFFFFu; co = o; cd = d; cinv = inv_d; }
-        if (sp == 0) { cur = REF_DONE; return; }
-        sp--;
-        cur = lds_stack[sp * LP_BLOCK + tid];
+        if constexpr (WIDE)
+        {
+            // entries are (reference, entry distance): one whose distance is no longer below the threshold is dropped unfetched.
+            // ONE entry per call: a dropped entry leaves REF_SKIP, and the lane pops again in its next node step -- a loop here
+            // would run for the whole wave as long as its unluckiest lane, at an LDS round trip per iteration.
+            if (sp == blas_base) { blas_base = 0xFFFFFFFFu; co = o; cd = d; cinv = inv_d; }
+            if (sp == 0) { cur = REF_DONE; return; }
+            sp--;
+            const uint32_t ref = lds_stack[(2u * sp) * LP_BLOCK + tid];
+            const float sd = __uint_as_float(lds_stack[(2u * sp + 1u) * LP_BLOCK + tid]);
+            cur = sd < wide_threshold(best.t, abs_margin) ? ref : REF_SKIP;
+        }
+        else
+        {
+            if (sp == blas_base) { blas_base = 0xFFFFFFFFu; co = o; cd = d; cinv = inv_d; }
+            if (sp == 0) { cur = REF_DONE; return; }
+            sp--;
+            cur = lds_stack[sp * LP_BLOCK + tid];
+        }
     };
+
+    // COUNT: how the wave's rounds were spent (work[LP_ROUND_BASE ..], MODE 0 only): refill rounds | N rounds, N steps, lanes
+    // over the N steps | T rounds, lanes | I rounds, lanes | F rounds, lanes
+    uint32_t rs[LP_ROUND_WORDS] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    unsigned long long clk[LP_CLOCK_WORDS] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    unsigned long long t_round = 0, t_loop = 0;
+    if (COUNT) t_loop = __builtin_amdgcn_s_memtime();
 
     // Phase scheduling: a lane is at an internal node (N), a TLAS leaf = instance entry (I), a triangle of a BLAS leaf (T),
     // at the end of a traversal (F) or empty (E).  Every round the wave executes the ONE phase most of its lanes wait for
@@ -458,6 +508,7 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
         if (cE >= refill_min && !exhausted)
         {
             // ---- refill empty lanes ----
+            if (COUNT) { rs[0]++; t_round = __builtin_amdgcn_s_memtime(); }
             const uint32_t my_rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             uint32_t first = 0;
             if (lane == 0) first = atomicAdd(cursor, cE);
@@ -465,14 +516,14 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
             const uint32_t take = first < cnt ? min(cE, cnt - first) : 0u;
             exhausted = take < cE;
             const bool got = !active && my_rank < take;
-            const size_t q_index = shard_base + first + my_rank;
+            const uint32_t job = first + my_rank;
             if (got && MODE == 0)
             {
-                slot = queue[q_index];
+                slot = queue[job];
                 const float4 orr = pb.ori_rng[slot];
                 const float4 dm = pb.dir_meta[slot];
                 bool trace = true;
-                if (TYPE == LUPIN_PATHTRACE_MIS)
+                if (TYPE == LUPIN_PATHTRACE_MIS && !RETRACE)
                 {
                     if (!(__float_as_uint(dm.w) & META_NEXT_EMISSION))   // reuse the BSDF-sampled hit (pathtracer.wgsl:751-755)
                     {
@@ -489,70 +540,115 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
                     in_medium = (__float_as_uint(dm.w) & META_VOLUME) != 0;
                     total_dst = 0.0f;
                     alpha_k = 0;
+                    flagged = false;
                     start_traversal();
                     active = true;
                 }
             }
             if (got && MODE == 1)
             {
-                const size_t job = q_index - shard_base;
-                slot = queue[shard_base + (job >> 1)];
-                ray_k = (uint32_t)(job & 1u);
+                if (RETRACE) { const uint32_t token = queue[job]; slot = token >> 1; ray_k = token & 1u; }
+                else { slot = queue[job >> 1]; ray_k = job & 1u; }
                 const float4 so = pb.sh_org[slot];
                 if (__float_as_uint(so.w) & (1u << ray_k))
                 {
                     const float4 dd = ray_k ? pb.sh_d1[slot] : pb.sh_d0[slot];
                     o = mk3(so.x, so.y, so.z);
                     d = mk3(dd.x, dd.y, dd.z);
+                    flagged = false;
                     start_traversal();
                     active = true;
                 }
             }
+            if (COUNT) clk[0] += __builtin_amdgcn_s_memtime() - t_round;
             continue;
         }
         if (cE == 64u) break;   // nothing in flight and (see above) nothing left to fetch
+        if (COUNT) t_round = __builtin_amdgcn_s_memtime();
+        int phase_id = 0;
 
         if (cN >= cT && cN >= cI && cN >= cF)
         {
             // ---- N: internal nodes of either level; keeps stepping while at least half of the voters are still at one ----
+            if (COUNT) { rs[1]++; phase_id = 1; }
             for (uint32_t r = 0;; r++)
             {
                 const bool n = active && !(cur & REF_LEAF);
                 if (r > 0 && (r >= nsteps || (uint32_t)__popcll(__ballot(n)) * 2u < cN)) break;
+                if (COUNT) { rs[2]++; rs[3] += (uint32_t)__popcll(__ballot(n)); }
                 if (n)
                 {
-                    const NodeRegs nd = geo.node(blas_base != 0xFFFFFFFFu, cur);
-                    float ld = slab_dst(co, cinv, nd.a.x, nd.a.y, nd.a.z, nd.a.w, nd.b.x, nd.b.y);
-                    float rd = slab_dst(co, cinv, nd.b.z, nd.b.w, nd.c.x, nd.c.y, nd.c.z, nd.c.w);
-                    bool left_first = ld <= rd;
-                    bool push_l = ld < best.t, push_r = rd < best.t;
-                    uint32_t near_ref = left_first ? nd.left : nd.right;
-                    uint32_t far_ref = left_first ? nd.right : nd.left;
-                    bool push_near = left_first ? push_l : push_r;
-                    bool push_far = left_first ? push_r : push_l;
-                    if (push_far) { lds_stack[sp * LP_BLOCK + tid] = far_ref; sp++; }
-                    if (push_near) cur = near_ref; else pop();
+                    if constexpr (WIDE)
+                    {
+                        bool need_pop = cur == REF_SKIP;
+                        if (!need_pop)
+                        {
+                            const auto nd = geo.node4(cur & REF_INDEX_MASK);
+                            float dk[4]; uint32_t rk[4];
+                            wide_children(nd, co, cinv, wide_threshold(best.t, abs_margin), dk, rk);
+                            if (2u * (sp + 3u) > stack_entries)
+                            {
+                                flagged = true; cur = REF_DONE;   // bounded stack (room for three is required): the binary tracer takes this query
+                            }
+                            else
+                            {
+                                #pragma unroll
+                                for (int k = 3; k >= 1; k--)
+                                    if (dk[k] < __builtin_inff())
+                                    {
+                                        lds_stack[(2u * sp) * LP_BLOCK + tid] = rk[k];
+                                        lds_stack[(2u * sp + 1u) * LP_BLOCK + tid] = __float_as_uint(dk[k]);
+                                        sp++;
+                                    }
+                                need_pop = !(dk[0] < __builtin_inff());
+                                cur = rk[0];
+                            }
+                        }
+                        if (need_pop) pop();
+                    }
+                    else
+                    {
+                        const NodeRegs nd = geo.node(blas_base != 0xFFFFFFFFu, cur);
+                        float ld = slab_dst(co, cinv, nd.a.x, nd.a.y, nd.a.z, nd.a.w, nd.b.x, nd.b.y);
+                        float rd = slab_dst(co, cinv, nd.b.z, nd.b.w, nd.c.x, nd.c.y, nd.c.z, nd.c.w);
+                        bool left_first = ld <= rd;
+                        bool push_l = ld < best.t, push_r = rd < best.t;
+                        uint32_t near_ref = left_first ? nd.left : nd.right;
+                        uint32_t far_ref = left_first ? nd.right : nd.left;
+                        bool push_near = left_first ? push_l : push_r;
+                        bool push_far = left_first ? push_r : push_l;
+                        if (push_far) { lds_stack[sp * LP_BLOCK + tid] = far_ref; sp++; }
+                        if (push_near) cur = near_ref; else pop();
+                    }
                 }
             }
         }
         else if (cT >= cI && cT >= cF)
         {
             // ---- T: one triangle of a BLAS leaf, first-found wins ties (strict <) ----
+            if (COUNT) { rs[4]++; rs[5] += cT; phase_id = 2; }
             if (isT)
             {
-                const uint32_t ti = cur & ~REF_LEAF;
+                const uint32_t ti = cur & (WIDE ? REF_INDEX_MASK : ~REF_LEAF);
                 const TriVerts tv = geo.tri(ti);
-                TriHit h = tri_dst(co, cd, xyz(tv.v0), xyz(tv.v1), xyz(tv.v2), eps);
-                if (h.t < best.t) { best.t = h.t; best.u = h.u; best.v = h.v; best.tri = ti; best.inst = cur_inst; }
-                if (__float_as_uint(tv.v0.w) & LEAF_END_BITS) pop(); else cur++;
+                bool give_up = false;
+                if constexpr (WIDE) give_up = wide_test_triangle(tv, ti, cur_inst, co, cd, eps, abs_margin, best);
+                else
+                {
+                    TriHit h = tri_dst(co, cd, xyz(tv.v0), xyz(tv.v1), xyz(tv.v2), eps);
+                    if (h.t < best.t) { best.t = h.t; best.u = h.u; best.v = h.v; best.tri = ti; best.inst = cur_inst; }
+                }
+                if (give_up) { flagged = true; cur = REF_DONE; }   // no certificate: the rest of this traversal would be discarded anyway
+                else if (__float_as_uint(tv.v0.w) & LEAF_END_BITS) pop(); else cur++;
             }
         }
         else if (cI >= cF)
         {
             // ---- I: enter an instance (bvh_custom.wgsl:28-37) ----
+            if (COUNT) { rs[6]++; rs[7] += cI; phase_id = 3; }
             if (isI)
             {
-                cur_inst = cur & ~REF_LEAF;
+                cur_inst = cur & (WIDE ? REF_INDEX_MASK : ~REF_LEAF);
                 const InstanceDev in = geo.inst(cur_inst);
                 co = mk3(o.x * in.r0.x + o.y * in.r0.y + o.z * in.r0.z + 1.0f * in.r0.w,
                          o.x * in.r1.x + o.y * in.r1.y + o.z * in.r1.z + 1.0f * in.r1.w,
@@ -560,15 +656,37 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
                 cd = mk3(d.x * in.r0.x + d.y * in.r0.y + d.z * in.r0.z + 0.0f * in.r0.w,
                          d.x * in.r1.x + d.y * in.r1.y + d.z * in.r1.z + 0.0f * in.r1.w,
                          d.x * in.r2.x + d.y * in.r2.y + d.z * in.r2.z + 0.0f * in.r2.w);
-                if (!(in.blas_root & REF_LEAF)) cinv = mk3(1.0f / cd.x, 1.0f / cd.y, 1.0f / cd.z);
+                uint32_t root = in.blas_root;
+                if constexpr (WIDE) root = geo.root4(cur_inst);
+                if (!(root & REF_LEAF)) cinv = mk3(1.0f / cd.x, 1.0f / cd.y, 1.0f / cd.z);
                 blas_base = sp;
-                cur = in.blas_root;
+                cur = root;
             }
         }
         else
         {
             // ---- F: end of a traversal = one iteration of ray_skip_alpha_stochastically (bvh_custom.wgsl:154-180) ----
-            if (isF && MODE == 1)
+            if (COUNT) { rs[8]++; rs[9] += cF; phase_id = 4; }
+            if constexpr (WIDE)
+            {
+                // queries without a certificate leave their token for the binary tracer and write nothing: the path state the
+                // re-trace starts from is the one this query started from (alpha skips included: the whole chain is redone)
+                const bool give_up = isF && flagged;
+                const unsigned long long gm = __ballot(give_up);
+                if (gm)
+                {
+                    uint32_t base = 0;
+                    const int leader = __ffsll((long long)gm) - 1;
+                    if ((int)lane == leader) base = atomicAdd(pb.retrace_counts + mode_row + shard, (uint32_t)__popcll(gm));
+                    base = __shfl(base, leader);
+                    if (give_up)
+                    {
+                        pb.retrace[2u * shard_base + base + (uint32_t)__popcll(gm & ((1ull << lane) - 1ull))] = MODE == 1 ? (slot * 2u + ray_k) : slot;
+                        active = false;
+                    }
+                }
+            }
+            if (isF && active && MODE == 1)
             {
                 const bool hit = best.t != LP_F32_MAX;
                 const float4 rec = make_float4(hit ? best.t : 0.0f, hit ? best.u : 0.0f, hit ? best.v : 0.0f, __uint_as_float(hit ? best.inst : HIT_MISS));
@@ -576,7 +694,7 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
                 else { pb.sh_hit1[slot] = rec; pb.sh_f1[slot].w = __uint_as_float(best.tri); }
                 active = false;
             }
-            if (isF && MODE == 0)
+            if (isF && active && MODE == 0)
             {
                 const bool hit = best.t != LP_F32_MAX;
                 bool again = false;
@@ -611,8 +729,85 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
                 }
             }
         }
+        if (COUNT)
+        {
+            // the wave must have received what the round loaded before the clock is read: this build measures, it does not race
+            __builtin_amdgcn_s_waitcnt(0);
+            clk[phase_id] += __builtin_amdgcn_s_memtime() - t_round;
+        }
     }
-    if (COUNT) tally_flush(tally, work + 3 * MODE);   // the loop ends wave-uniformly: all lanes are here
+    if (COUNT) tally_flush(tally, work + LP_TALLY * MODE);   // the loop ends wave-uniformly: all lanes are here
+    if (COUNT && MODE == 0 && !RETRACE && lane == 0)
+    {
+        clk[5] = __builtin_amdgcn_s_memtime() - t_loop;
+        for (int k = 0; k < LP_ROUND_WORDS; k++) if (rs[k]) atomicAdd(&work[LP_ROUND_BASE + k], (unsigned long long)rs[k]);
+        for (int k = 0; k < LP_CLOCK_WORDS; k++) if (clk[k]) atomicAdd(&work[LP_CLOCK_BASE + k], clk[k]);
+    }
+}
+
+// LUPIN_VERIFY_WIDE=1 (checker, not product): before the tracing stage of an iteration, every queued path's first closest-hit
+// query is run twice by one thread -- the reference's binary order and the four-wide traversal -- and compared word for word.
+// verify[0] rays checked, [1] rays the wide traversal flagged (the product re-traces those), [2] UNFLAGGED rays whose wide
+// result differs (the certificate's claim is that this stays 0), [3] rays that differ, flagged or not, [4..7] flagged rays by
+// reason (second hit within the margin | ill-conditioned hit | triangle outside a box above it | stack bound); a ray can
+// have several.
+template <int MODE>   // 0: the queued paths' next closest-hit query; 1: the shadow rays k_shade recorded (two per entry)
+__global__ void __launch_bounds__(LP_BLOCK) k_verify_wide(SceneDev sc, const FrameParams *__restrict__ fpp, PathBuffers pb, uint32_t iter,
+                                                          uint32_t wide_pairs, unsigned long long *verify)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
+    const uint32_t shard = blockIdx.x % LP_SHARDS;
+    const uint32_t count = pb.counts[iter * LP_SHARDS + shard];
+    const uint32_t i = (blockIdx.x / LP_SHARDS) * LP_BLOCK + threadIdx.x;
+    uint32_t checked = 0, flagged = 0, bad = 0, raw = 0, why_tie = 0, why_cond = 0, why_leaky = 0, why_stack = 0;
+    const float eps = fpp->pc.ray_epsilon;
+    const auto geo = geo_global(sc);
+    for (uint32_t k = 0; k < (MODE == 1 ? 2u : 1u); k++)
+    {
+        bool have = i < count;
+        f3 o = splat(0.0f), d = mk3(0.0f, 0.0f, 1.0f);
+        if (have)
+        {
+            const uint32_t slot = pb.queue[iter & 1][(size_t)shard * pb.shard_cap + i];
+            if (MODE == 0)
+            {
+                const float4 orr = pb.ori_rng[slot], dm = pb.dir_meta[slot];
+                o = mk3(orr.x, orr.y, orr.z); d = mk3(dm.x, dm.y, dm.z);
+            }
+            else
+            {
+                const float4 so = pb.sh_org[slot];
+                have = (__float_as_uint(so.w) & (1u << k)) != 0;
+                const float4 dd = k ? pb.sh_d1[slot] : pb.sh_d0[slot];
+                o = mk3(so.x, so.y, so.z); d = mk3(dd.x, dd.y, dd.z);
+            }
+        }
+        if (have)
+        {
+            const Closest a = scene_closest(geo, sc, lds_stack, o, d, eps);
+            bool flag;
+            uint32_t why = 0u;
+            const Closest b = scene_closest_wide(geo, sc, lds_stack, wide_pairs, o, d, eps, flag, &why);
+            why_tie += (why & WIDE_WHY_TIE) ? 1u : 0u; why_cond += (why & WIDE_WHY_CONDITION) ? 1u : 0u;
+            why_leaky += (why & WIDE_WHY_LEAKY) ? 1u : 0u; why_stack += (why & WIDE_WHY_STACK) ? 1u : 0u;
+            const bool miss_a = a.t == LP_F32_MAX, miss_b = b.t == LP_F32_MAX;
+            const bool same = (miss_a && miss_b) || (!miss_a && !miss_b && __float_as_uint(a.t) == __float_as_uint(b.t) && __float_as_uint(a.u) == __float_as_uint(b.u) &&
+                                                     __float_as_uint(a.v) == __float_as_uint(b.v) && a.tri == b.tri && a.inst == b.inst);
+            checked += 1u; flagged += flag ? 1u : 0u; raw += same ? 0u : 1u; bad += (!same && !flag) ? 1u : 0u;
+            if (!same && !flag)
+                printf("[lupin verify] uncertified difference: mode %d o %a %a %a d %a %a %a | binary t %a tri %u inst %u | wide t %a tri %u inst %u\n", MODE,
+                       o.x, o.y, o.z, d.x, d.y, d.z, a.t, a.tri, a.inst, b.t, b.tri, b.inst);
+        }
+    }
+    uint32_t v[8] = {checked, flagged, bad, raw, why_tie, why_cond, why_leaky, why_stack};
+    #pragma unroll
+    for (int k = 0; k < 8; k++)
+    {
+        uint32_t x = v[k];
+        #pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+        if ((threadIdx.x & 63u) == 0u && x) atomicAdd(&verify[k], (unsigned long long)x);
+    }
 }
 
 // clamp_radiance (pathtracer.wgsl:1774-1783)
@@ -1708,6 +1903,27 @@ __global__ void __launch_bounds__(LP_BLOCK) k_trace(SceneDev sc, uint32_t n, con
     f3 d = mk3(dir[i * 3 + 0], dir[i * 3 + 1], dir[i * 3 + 2]);
     Closest c = scene_closest(geo_global(sc), sc, lds_stack, o, d, eps);
     bool hit = c.t != LP_F32_MAX;
+    out_hit[i] = hit ? 1u : 0u;
+    out_dst[i] = hit ? c.t : 0.0f;
+    out_uv[i * 2 + 0] = hit ? c.u : 0.0f;
+    out_uv[i * 2 + 1] = hit ? c.v : 0.0f;
+    out_inst[i] = hit ? c.inst : 0u;
+    out_tri[i] = hit ? (c.tri - sc.meshes[sc.instances[c.inst].mesh_idx].tri_offset) : 0u;
+}
+
+// the same probe through the four-wide traversal; out_flag = the traversal asks for a re-trace (its result is then unspecified)
+__global__ void __launch_bounds__(LP_BLOCK) k_trace_wide(SceneDev sc, uint32_t n, const float *ori, const float *dir, float eps, uint32_t wide_pairs,
+                                                         uint32_t *out_hit, float *out_dst, float *out_uv, uint32_t *out_inst, uint32_t *out_tri, uint32_t *out_flag)
+{
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t i = blockIdx.x * LP_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    f3 o = mk3(ori[i * 3 + 0], ori[i * 3 + 1], ori[i * 3 + 2]);
+    f3 d = mk3(dir[i * 3 + 0], dir[i * 3 + 1], dir[i * 3 + 2]);
+    bool flag;
+    Closest c = scene_closest_wide(geo_global(sc), sc, lds_stack, wide_pairs, o, d, eps, flag);
+    bool hit = c.t != LP_F32_MAX;
+    out_flag[i] = flag ? 1u : 0u;
     out_hit[i] = hit ? 1u : 0u;
     out_dst[i] = hit ? c.t : 0.0f;
     out_uv[i * 2 + 0] = hit ? c.u : 0.0f;

@@ -74,10 +74,26 @@ def test_baseline_config_at_full_size(gpu_ctx, label, name, cam_i, W, H, bounces
     ref = np.zeros((H, W, 4), np.float16)
     for t in pick_tiles(ts, W, H, fractions):
         tp = api.TileParams(tile_size=ts, tile_idx=t)
+        # the default (wide tracer + re-trace) first: counters of its own layout, image compared below
+        gpu_ctx.stats_reset(2)
+        api.pathtrace_scene(gpu_ctx, res, scene, tex, 0, api.PathtraceDesc(camera_params=params, camera_transform=cam.transform, tile_params=tp))
+        wst = gpu_ctx.stats()
+        wide_img = tex.download()
+        assert wst["wide_traversal"] == 1 and wst["wide_node_visits"][0] > 0 and wst["wide_queries"] >= wst["path_bounces"]
+        # then the reference's order alone, whose work must equal the oracle's count for count
+        gpu_ctx.set_traversal("binary")
         gpu_ctx.stats_reset(2)
         api.pathtrace_scene(gpu_ctx, res, scene, tex, 0, api.PathtraceDesc(camera_params=params, camera_transform=cam.transform, tile_params=tp))
         st = gpu_ctx.stats()
+        gpu_ctx.set_traversal("wide")
         gpu_ctx.stats_reset(0)
+        assert st["wide_traversal"] == 0 and util.f16_words_differ(wide_img, tex.download()) == 0
+        # a wide-node visit replaces up to three of the binary tree's (deep BLASes: about two; a sky tile that only touches the
+        # top of the TLAS: hardly any), and the re-traced share is small
+        print(f"{label} tile {t}: node fetches per path-bounce {st['node_visits'][0] / st['path_bounces']:.1f} binary -> "
+              f"{(wst['wide_node_visits'][0] + wst['node_visits'][0]) / st['path_bounces']:.1f} wide + re-trace")
+        assert wst["wide_node_visits"][0] + wst["node_visits"][0] < st["node_visits"][0], f"{label}: tile {t}"
+        assert wst["wide_retraced"] < 0.06 * wst["wide_queries"]
         _, cnt = oracle.pathtrace(scene, W, H, params, cam.transform, bounces, spp, 0, tile_params=tp, out=ref)
         (ox, oy), gx, gy = oracle.dispatch_extent(W, H, tp)
         assert gx == gy == ts
@@ -168,7 +184,7 @@ def test_work_counting_does_not_change_the_image(gpu_ctx):
         gpu_ctx.stats_reset(0)
         assert util.f16_words_differ(a.download(), b.download()) == 0
         assert plain["path_bounces"] == counted["path_bounces"] and plain["node_visits"] == [0, 0, 0]
-        assert counted["node_visits"][0] > 0 and counted["tri_tests"][0] > 0 and counted["instance_entries"][0] > 0
+        assert counted["node_visits"][0] + counted["wide_node_visits"][0] > 0 and counted["tri_tests"][0] > 0 and counted["instance_entries"][0] > 0
 
 
 def test_measured_copy_bandwidth_and_runtime(gpu_ctx):
