@@ -186,8 +186,8 @@ class Context:
         check(lib().lupin_hip_reserve_path_state(self.handle, int(pixels), int(max_bounces), int(samples_per_pixel)))
 
     def set_traversal(self, mode):
-        """"wide" (default: four-wide hierarchy + exactness certificate + re-trace) or "binary" (the reference's order only)."""
-        check(lib().lupin_hip_set_traversal(self.handle, {"wide": 0, "binary": 1}[mode]))
+        """"binary" (default: the reference's visiting order) or "wide" (four-wide hierarchy + exactness certificate + re-trace)."""
+        check(lib().lupin_hip_set_traversal(self.handle, {"binary": 0, "wide": 1}[mode]))
 
     def set_accumulation_mode(self, mode):
         """0 = f16 running average (reference-faithful, default), 1 = f32 accumulator per texture (pathtracer.wgsl:275-289)."""

@@ -46,11 +46,16 @@ constexpr uint32_t TRI_LEAKY_BITS = 2u;   // TriVerts.v0.w: the triangle is not 
 // needs.
 struct WideNode
 {
-    float4 a;  // l.min.x l.min.y l.min.z l.max.x
-    float4 b;  // l.max.y l.max.z r.min.x r.min.y
-    float4 c;  // r.min.z r.max.x r.max.y r.max.z
-    uint4 d;   // left_ref right_ref 0 0
+    // the two children's bounds interleaved (left, right per coordinate): a load leaves each (left, right) pair in two
+    // consecutive registers, which is what the packed slab arithmetic (slab_pair) consumes
+    float4 a;  // l.min.x r.min.x l.min.y r.min.y
+    float4 b;  // l.min.z r.min.z l.max.x r.max.x
+    float4 c;  // l.max.y r.max.y l.max.z r.max.z
+    uint4 d;   // left_ref right_ref flags 0   (flags: bit 0 / 1 = the left / right child's box does not bound its triangles)
 };
+// slab_dst on the left / right child of a node in that layout
+#define LP_NODE_LEFT(nd)  (nd).a.x, (nd).a.z, (nd).b.x, (nd).b.z, (nd).c.x, (nd).c.z
+#define LP_NODE_RIGHT(nd) (nd).a.y, (nd).a.w, (nd).b.y, (nd).b.w, (nd).c.y, (nd).c.w
 
 // The same hierarchies collapsed to four children per node (lupin_hip_scene_create: a node's grandchildren are pulled up,
 // largest box first, until it has four children or only leaves): one 128-byte line = one L1-miss request, which costs the
@@ -110,7 +115,7 @@ struct AliasRange { uint32_t offset, count; };
 struct SceneDev
 {
     const WideNode *tlas;        uint32_t tlas_root;   // child reference
-    const WideNode *blas;
+    const WideNode *blas;        // ONE array holds both hierarchies ([BLAS nodes of every mesh | TLAS nodes]; tlas == blas): node references are indices into it
     const TriVerts *tris;
     const uint32_t *tri_indices; // 3 per global triangle, mesh-local vertex ids
     const InstanceDev *instances;
@@ -231,16 +236,32 @@ LP_DEV uint32_t rnd_range(uint32_t &s, uint32_t max_exclusive)
 // Slab test (pathtracer.wgsl:2906-2917).  min/max here are IEEE minNum/maxNum (v_min_f32 / v_max_f32 /
 // v_min3 / v_max3 on gfx950, fminf/fmaxf in the oracle): WGSL lets min/max return either operand when one is
 // NaN, and the results only feed comparisons, so the sign of a zero is immaterial.
-LP_DEV float slab_dst(f3 o, f3 inv_d, float lox, float loy, float loz, float hix, float hiy, float hiz)
+LP_DEV float slab_finish(float tminx, float tmaxx, float tminy, float tmaxy, float tminz, float tmaxz)
 {
-    float tminx = (lox - o.x) * inv_d.x, tminy = (loy - o.y) * inv_d.y, tminz = (loz - o.z) * inv_d.z;
-    float tmaxx = (hix - o.x) * inv_d.x, tmaxy = (hiy - o.y) * inv_d.y, tmaxz = (hiz - o.z) * inv_d.z;
     float t1x = __builtin_fminf(tminx, tmaxx), t1y = __builtin_fminf(tminy, tmaxy), t1z = __builtin_fminf(tminz, tmaxz);
     float t2x = __builtin_fmaxf(tminx, tmaxx), t2y = __builtin_fmaxf(tminy, tmaxy), t2z = __builtin_fmaxf(tminz, tmaxz);
     float dst_far = __builtin_fminf(__builtin_fminf(t2x, t2y), t2z);
     float dst_near = __builtin_fmaxf(__builtin_fmaxf(t1x, t1y), t1z);
     bool did_hit = dst_far >= dst_near && dst_far > 0.0f;
     return did_hit ? dst_near : LP_F32_MAX;
+}
+LP_DEV float slab_dst(f3 o, f3 inv_d, float lox, float loy, float loz, float hix, float hiy, float hiz)
+{
+    float tminx = (lox - o.x) * inv_d.x, tminy = (loy - o.y) * inv_d.y, tminz = (loz - o.z) * inv_d.z;
+    float tmaxx = (hix - o.x) * inv_d.x, tmaxy = (hiy - o.y) * inv_d.y, tmaxz = (hiz - o.z) * inv_d.z;
+    return slab_finish(tminx, tmaxx, tminy, tmaxy, tminz, tmaxz);
+}
+// slab_dst of both children of a child-pair node at once: the same IEEE subtractions and multiplications, issued as packed
+// instructions (v_pk_add_f32 / v_pk_mul_f32 compute two independent IEEE results), then slab_dst's own tail per child.
+typedef float lp_v2 __attribute__((ext_vector_type(2)));
+LP_DEV void slab_pair(f3 o, f3 inv_d, float4 a, float4 b, float4 c, float &ld, float &rd)
+{
+    const lp_v2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+    const lp_v2 ix = {inv_d.x, inv_d.x}, iy = {inv_d.y, inv_d.y}, iz = {inv_d.z, inv_d.z};
+    const lp_v2 tminx = ((lp_v2){a.x, a.y} - ox) * ix, tminy = ((lp_v2){a.z, a.w} - oy) * iy, tminz = ((lp_v2){b.x, b.y} - oz) * iz;
+    const lp_v2 tmaxx = ((lp_v2){b.z, b.w} - ox) * ix, tmaxy = ((lp_v2){c.x, c.y} - oy) * iy, tmaxz = ((lp_v2){c.z, c.w} - oz) * iz;
+    ld = slab_finish(tminx.x, tmaxx.x, tminy.x, tmaxy.x, tminz.x, tmaxz.x);
+    rd = slab_finish(tminx.y, tmaxx.y, tminy.y, tmaxy.y, tminz.y, tmaxz.y);
 }
 
 struct TriHit { float t, u, v; };
@@ -278,9 +299,9 @@ struct GeoGlobal
     const WideNode *tlas, *blas;
     const TriVerts *tris;
     const InstanceDev *instances;
-    LP_DEV NodeRegs node(bool in_blas, uint32_t i) const
+    LP_DEV NodeRegs node(bool, uint32_t i) const   // TLAS and BLAS nodes share one array: references are global indices
     {
-        const WideNode nd = (in_blas ? blas : tlas)[i];
+        const WideNode nd = blas[i];
         NodeRegs r; r.a = nd.a; r.b = nd.b; r.c = nd.c; r.left = nd.d.x; r.right = nd.d.y;
         return r;
     }
@@ -305,9 +326,9 @@ struct GeoLds
     lds_v4p base;
     uint32_t off_blas, off_tris, off_inst;
     static LP_DEV float4 f4(v4f v) { return make_float4(v.x, v.y, v.z, v.w); }
-    LP_DEV NodeRegs node(bool in_blas, uint32_t i) const
+    LP_DEV NodeRegs node(bool, uint32_t i) const
     {
-        lds_v4p p = base + (in_blas ? off_blas : 0u) + i * LP_GEO_LDS_STRIDE;
+        lds_v4p p = base + i * LP_GEO_LDS_STRIDE;   // [BLAS | TLAS] in the blob: global node indices, like GeoGlobal
         const v4f a = p[0], b = p[1], c = p[2], d = p[3];
         NodeRegs r; r.a = f4(a); r.b = f4(b); r.c = f4(c); r.left = __float_as_uint(d.x); r.right = __float_as_uint(d.y);
         return r;
@@ -427,8 +448,8 @@ LP_DEV bool blas_closest(const Geo &geo, uint32_t *stack, uint32_t sp_base, uint
         else
         {
             const NodeRegs nd = geo.node(true, cur);
-            float ld = slab_dst(o, inv_d, nd.a.x, nd.a.y, nd.a.z, nd.a.w, nd.b.x, nd.b.y);
-            float rd = slab_dst(o, inv_d, nd.b.z, nd.b.w, nd.c.x, nd.c.y, nd.c.z, nd.c.w);
+            float ld = slab_dst(o, inv_d, LP_NODE_LEFT(nd));
+            float rd = slab_dst(o, inv_d, LP_NODE_RIGHT(nd));
             bool left_first = ld <= rd;
             bool push_l = ld < best.t, push_r = rd < best.t;
             uint32_t near_ref = left_first ? nd.left : nd.right;
@@ -486,8 +507,8 @@ LP_DEV Closest scene_closest(const Geo &geo, const SceneDev &sc, uint32_t *stack
         while (!(cur & REF_LEAF))
         {
             const NodeRegs nd = geo.node(blas_base != 0xFFFFFFFFu, cur);
-            float ld = slab_dst(co, cinv, nd.a.x, nd.a.y, nd.a.z, nd.a.w, nd.b.x, nd.b.y);
-            float rd = slab_dst(co, cinv, nd.b.z, nd.b.w, nd.c.x, nd.c.y, nd.c.z, nd.c.w);
+            float ld = slab_dst(co, cinv, LP_NODE_LEFT(nd));
+            float rd = slab_dst(co, cinv, LP_NODE_RIGHT(nd));
             bool left_first = ld <= rd;
             bool push_l = ld < best.t, push_r = rd < best.t;
             uint32_t near_ref = left_first ? nd.left : nd.right;
@@ -550,7 +571,7 @@ LP_DEV Closest scene_closest(const Geo &geo, const SceneDev &sc, uint32_t *stack
 // margin above the final best IS tested; (2) raises `flag` when it tests a second triangle hit inside that margin of the
 // current best, or a hit whose intersection is ill-conditioned (wide_hit_is_ill_conditioned) or whose triangle is marked as
 // outside a box above it (TRI_LEAKY_BITS), or when its bounded stack would overflow; (3) never prunes by distance a child
-// whose box does not bound its triangles (Wide4.pad.x).  An unflagged ray's (t, u, v, triangle, instance) is the reference's: with m' the conditioning bound and
+// whose box does not bound its triangles (REF_LEAKY).  An unflagged ray's (t, u, v, triangle, instance) is the reference's: with m' the conditioning bound and
 // (1 + m')^2 < 1 + m, the reference's winner R and this traversal's winner W each pass the other's pruning (their boxes'
 // entry distances are below t_W (1 + m) resp. the reference's best at every moment), so both traversals test both; W != R
 // would be a second hit inside the margin -> flagged.  Flagged rays are re-traced by the binary kernel, which IS the
@@ -569,7 +590,6 @@ LP_DEV float wide_threshold(float best_t, float abs_margin)
 // Returns the number of children to visit; dk / rk hold them nearest first.  The slab arithmetic is slab_dst's, operation
 // for operation (same IEEE subtractions, multiplications, minNum / maxNum), written on pairs of children so that the
 // subtractions and multiplications issue as packed instructions (v_pk_add_f32 / v_pk_mul_f32: two IEEE results each).
-typedef float lp_v2 __attribute__((ext_vector_type(2)));
 // slab_dst's verdict from the six per-axis distances, as the child's sort key: dst_near when the slab test hits, +inf when
 // it misses (slab_dst returns MAX there; every use below only asks "below the threshold?" / "hit at all?").  Three chained
 // selects: each comparison feeds its own select, no mask arithmetic.
@@ -672,7 +692,7 @@ LP_DEV Closest scene_closest_wide(const Geo &geo, const SceneDev &sc, uint32_t *
 {
     const uint32_t tid = threadIdx.x;
     constexpr uint32_t REF_DONE = 0xFFFFFFFFu;
-    const float abs_margin = 0.25f * eps;
+    const float abs_margin = eps;
     Closest best;
     best.t = LP_F32_MAX; best.u = 0.0f; best.v = 0.0f; best.tri = 0u; best.inst = 0xFFFFFFFFu;
     flag = false;

@@ -95,7 +95,7 @@ struct LupinContext
     bool use_graph = false;                 // LUPIN_GRAPH=1: replay the lane-private wavefront as a HIP graph (opt-in)
     bool persistent_shadow = true;          // LUPIN_SHADOW=simple: MIS / Direct shadow rays stay in k_shadow even on large scenes
     uint32_t node_steps = 4;               // LUPIN_NODE_STEPS: node visits per scheduling round of k_extend_persistent
-    bool wide_traversal = true;            // LUPIN_TRAVERSAL=binary: the persistent tracer walks the reference's binary hierarchy only
+    bool wide_traversal = false;           // LUPIN_TRAVERSAL=wide / lupin_hip_set_traversal: four-wide hierarchy + certificate + re-trace (same images, not faster: DESIGN 5)
     uint32_t wide_stack_pairs = 20;        // LUPIN_WIDE_STACK: (reference, distance) stack entries per lane of the wide tracer
     bool verify_wide = false;              // LUPIN_VERIFY_WIDE=1: every closest-hit query is also checked wide-vs-binary on the device (stats)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_extend, ev_shade, ev_total;
@@ -249,8 +249,8 @@ static uint32_t collapse_to_wide4(const std::vector<WideNode> &bin, uint32_t roo
     struct Child { float lo[3], hi[3]; uint32_t ref; bool leaky, closed; };
     auto children_of = [&](uint32_t b, Child &l, Child &r) {
         const WideNode &w = bin[b];
-        l.lo[0] = w.a.x; l.lo[1] = w.a.y; l.lo[2] = w.a.z; l.hi[0] = w.a.w; l.hi[1] = w.b.x; l.hi[2] = w.b.y; l.ref = w.d.x;
-        r.lo[0] = w.b.z; r.lo[1] = w.b.w; r.lo[2] = w.c.x; r.hi[0] = w.c.y; r.hi[1] = w.c.z; r.hi[2] = w.c.w; r.ref = w.d.y;
+        l.lo[0] = w.a.x; l.lo[1] = w.a.z; l.lo[2] = w.b.x; l.hi[0] = w.b.z; l.hi[1] = w.c.x; l.hi[2] = w.c.z; l.ref = w.d.x;
+        r.lo[0] = w.a.y; r.lo[1] = w.a.w; r.lo[2] = w.b.y; r.hi[0] = w.b.w; r.hi[1] = w.c.y; r.hi[2] = w.c.w; r.ref = w.d.y;
         l.leaky = (w.d.z & 1u) != 0; r.leaky = (w.d.z & 2u) != 0;
         l.closed = r.closed = false;
     };
@@ -440,9 +440,9 @@ static uint32_t blas_child_pairs(const LupinBvhNode *nodes, uint32_t num_nodes, 
         const LupinBvhNode &l = nodes[lc];
         const LupinBvhNode &r = nodes[rc];
         WideNode w;
-        w.a = make_float4(l.aabb_min[0], l.aabb_min[1], l.aabb_min[2], l.aabb_max[0]);
-        w.b = make_float4(l.aabb_max[1], l.aabb_max[2], r.aabb_min[0], r.aabb_min[1]);
-        w.c = make_float4(r.aabb_min[2], r.aabb_max[0], r.aabb_max[1], r.aabb_max[2]);
+        w.a = make_float4(l.aabb_min[0], r.aabb_min[0], l.aabb_min[1], r.aabb_min[1]);
+        w.b = make_float4(l.aabb_min[2], r.aabb_min[2], l.aabb_max[0], r.aabb_max[0]);
+        w.c = make_float4(l.aabb_max[1], r.aabb_max[1], l.aabb_max[2], r.aabb_max[2]);
         w.d = make_uint4(ref[lc], ref[rc], (leaky_node[lc] ? 1u : 0u) | (leaky_node[rc] ? 2u : 0u), 0u);
         blas[ref[n]] = w;
     }
@@ -863,7 +863,7 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
     if (shd && strcmp(shd, "simple") == 0) ctx->persistent_shadow = false;
     const char *ns = getenv("LUPIN_NODE_STEPS");
     if (ns) ctx->node_steps = (uint32_t)std::min(16, std::max(1, atoi(ns)));
-    if (const char *tv = getenv("LUPIN_TRAVERSAL")) ctx->wide_traversal = strcmp(tv, "binary") != 0;
+    if (const char *tv = getenv("LUPIN_TRAVERSAL")) ctx->wide_traversal = strcmp(tv, "wide") == 0;
     if (const char *ws = getenv("LUPIN_WIDE_STACK")) ctx->wide_stack_pairs = (uint32_t)std::min(64, std::max(4, atoi(ws)));
     if (const char *vw = getenv("LUPIN_VERIFY_WIDE")) ctx->verify_wide = atoi(vw) != 0;
     const char *rm = getenv("LUPIN_REFILL_MIN");
@@ -1115,7 +1115,9 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
     uint32_t tlas_depth = 0;
     if (s.num_tlas_nodes > 0)
     {
+        // TLAS nodes go behind the BLAS nodes in ONE array (no per-lane base select in the traversal step): global references
         std::vector<uint32_t> ref(s.num_tlas_nodes);
+        const uint32_t nblas = (uint32_t)blas.size();
         uint32_t wide_count = 0;
         for (uint32_t n = 0; n < s.num_tlas_nodes; n++)
         {
@@ -1128,7 +1130,7 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
             else
             {
                 if (nd.left >= s.num_tlas_nodes || nd.right >= s.num_tlas_nodes) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "TLAS child out of range"); }
-                ref[n] = wide_count++;
+                ref[n] = nblas + wide_count++;
             }
         }
         tlas.resize(wide_count);
@@ -1139,11 +1141,11 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
             const LupinTlasNode &l = s.tlas_nodes[nd.left];
             const LupinTlasNode &r = s.tlas_nodes[nd.right];
             WideNode w;
-            w.a = make_float4(l.aabb_min[0], l.aabb_min[1], l.aabb_min[2], l.aabb_max[0]);
-            w.b = make_float4(l.aabb_max[1], l.aabb_max[2], r.aabb_min[0], r.aabb_min[1]);
-            w.c = make_float4(r.aabb_min[2], r.aabb_max[0], r.aabb_max[1], r.aabb_max[2]);
+            w.a = make_float4(l.aabb_min[0], r.aabb_min[0], l.aabb_min[1], r.aabb_min[1]);
+            w.b = make_float4(l.aabb_min[2], r.aabb_min[2], l.aabb_max[0], r.aabb_max[0]);
+            w.c = make_float4(l.aabb_max[1], r.aabb_max[1], l.aabb_max[2], r.aabb_max[2]);
             w.d = make_uint4(ref[nd.left], ref[nd.right], 0u, 0u);
-            tlas[ref[n]] = w;
+            tlas[ref[n] - nblas] = w;
         }
         tlas_root = ref[0];
         // depth from the root (bounded walk: a malformed cyclic TLAS is rejected)
@@ -1164,16 +1166,17 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
         }
     }
     sc->stack_entries = tlas_depth + max_blas_depth + 1;
+    blas.insert(blas.end(), tlas.begin(), tlas.end());   // the one node array: [BLAS | TLAS]
 
     // ---- the same hierarchies four-wide (wide tracer; scenes small enough for LDS staging are traced by k_extend) ----
     std::vector<Wide4> wide4;   // TLAS nodes first, then every mesh's BLAS nodes: one array, global indices
     std::vector<uint32_t> mesh_root4(s.num_meshes, REF_LEAF);
     uint32_t tlas4_root = tlas_root;
-    const size_t lds_bytes_if_staged = tlas.size() * 80 + blas.size() * 80 + tris.size() * 48 + (size_t)s.num_instances * 80;
+    const size_t lds_bytes_if_staged = blas.size() * 80 + tris.size() * 48 + (size_t)s.num_instances * 80;
     const bool build_wide = s.num_instances > 0 && !(lds_bytes_if_staged <= LP_GEO_LDS_LIMIT && ctx->lds_geometry);
     if (build_wide)
     {
-        tlas4_root = collapse_to_wide4(tlas, tlas_root, wide4);
+        tlas4_root = collapse_to_wide4(blas, tlas_root, wide4);
         for (uint32_t mi = 0; mi < s.num_meshes; mi++) mesh_root4[mi] = collapse_to_wide4(blas, mesh_root[mi], wide4);
         if (wide4.size() >= (size_t)REF_INDEX_MASK || tris.size() >= (size_t)REF_INDEX_MASK) { lupin_hip_scene_destroy(sc); return fail(LUPIN_ERR_INVALID_ARGUMENT, "scene too large for 30-bit references"); }
         sc->has_wide = true;
@@ -1292,7 +1295,7 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
     std::vector<float4> geo_blob;
     uint32_t off_blas = 0, off_tris = 0, off_inst = 0;
     {
-        const size_t bytes = tlas.size() * 80 + blas.size() * 80 + tris.size() * 48 + instances.size() * 80;
+        const size_t bytes = blas.size() * 80 + tris.size() * 48 + instances.size() * 80;
         if (bytes > 0 && bytes <= LP_GEO_LDS_LIMIT)
         {
             auto append = [&](const void *p, size_t count, size_t words) {   // records of `words` 16-byte words, padded to LP_GEO_LDS_STRIDE
@@ -1303,9 +1306,8 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
                     if (words == 4) geo_blob.push_back(make_float4(0.0f, 0.0f, 0.0f, 0.0f));
                 }
             };
-            append(tlas.data(), tlas.size(), 4);
-            off_blas = (uint32_t)geo_blob.size();
-            append(blas.data(), blas.size(), 4);
+            append(blas.data(), blas.size(), 4);   // [BLAS | TLAS] nodes, indexed by the global references
+            off_blas = 0;
             off_tris = (uint32_t)geo_blob.size();
             append(tris.data(), tris.size(), 3);
             off_inst = (uint32_t)geo_blob.size();
@@ -1318,7 +1320,7 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
     std::vector<LupinMaterial> materials(s.materials, s.materials + s.num_materials);
     std::vector<LupinEnvironment> envs(s.environments, s.environments + s.num_environments);
     std::vector<LupinLight> lights(s.lights, s.lights + s.num_lights);
-    if ((rc = upload(sc, tlas, &dv.tlas)) || (rc = upload(sc, blas, &dv.blas)) || (rc = upload(sc, tris, &dv.tris)) ||
+    if ((rc = upload(sc, blas, &dv.blas)) || (rc = upload(sc, tris, &dv.tris)) ||
         (rc = upload(sc, tri_indices, &dv.tri_indices)) || (rc = upload(sc, instances, &dv.instances)) ||
         (rc = upload(sc, meshes, &dv.meshes)) || (rc = upload(sc, materials, &dv.materials)) ||
         (rc = upload(sc, normals, &dv.normals)) || (rc = upload(sc, texcoords, &dv.texcoords)) || (rc = upload(sc, colors, &dv.colors)) ||
@@ -1332,6 +1334,7 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
         lupin_hip_scene_destroy(sc);
         return rc;
     }
+    dv.tlas = dv.blas;
     dv.tlas_root = tlas_root;
     dv.tlas4_root = tlas4_root;
     dv.num_lights = s.num_lights;

@@ -437,8 +437,9 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
     bool exhausted = false;                                                 // wave-uniform: the shard's queue is handed out
 
     const float eps = fp.pc.ray_epsilon;
-    const float abs_margin = 0.25f * eps;                                   // wide_threshold's absolute part
+    const float abs_margin = eps;                                           // wide_threshold's absolute part: the scene's own "closer than this is the same place"
     constexpr uint32_t REF_DONE = 0xFFFFFFFFu;
+    constexpr uint32_t REF_EXIT = 0xFFFFFFFEu;                              // "leave the instance": handled with the instance entries (I phase), see pop()
     constexpr uint32_t REF_SKIP = 0x3FFFFFFFu;                              // WIDE: "pop again" -- an internal-node reference no scene can hold (index 2^30 - 1)
     const uint32_t stack_entries = stack_words / LP_BLOCK;                  // WIDE: (reference, distance) pairs -> stack_entries / 2 of them
 
@@ -461,26 +462,24 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
         cur = sc.num_instances ? (WIDE ? sc.tlas4_root : sc.tlas_root) : REF_DONE;
         best.t = LP_F32_MAX; best.u = 0.0f; best.v = 0.0f; best.tri = 0u; best.inst = HIT_MISS;
     };
+    // The next reference of the lane's stack.  An exhausted BLAS part (sp == blas_base) does NOT restore the world ray here:
+    // that is nine registers assigned under a condition inside the hottest loop, which the compiler pays for with copies of
+    // the whole ray at every join (a third of the node step's vector instructions were v_mov).  The lane takes REF_EXIT
+    // instead, which the top of the next scheduling round serves (restore, then pop on) before the phases are counted.
     auto pop = [&]() {
+        if (sp == blas_base) { cur = REF_EXIT; return; }
+        if (sp == 0) { cur = REF_DONE; return; }
+        sp--;
         if constexpr (WIDE)
         {
             // entries are (reference, entry distance): one whose distance is no longer below the threshold is dropped unfetched.
             // ONE entry per call: a dropped entry leaves REF_SKIP, and the lane pops again in its next node step -- a loop here
             // would run for the whole wave as long as its unluckiest lane, at an LDS round trip per iteration.
-            if (sp == blas_base) { blas_base = 0xFFFFFFFFu; co = o; cd = d; cinv = inv_d; }
-            if (sp == 0) { cur = REF_DONE; return; }
-            sp--;
             const uint32_t ref = lds_stack[(2u * sp) * LP_BLOCK + tid];
             const float sd = __uint_as_float(lds_stack[(2u * sp + 1u) * LP_BLOCK + tid]);
             cur = sd < wide_threshold(best.t, abs_margin) ? ref : REF_SKIP;
         }
-        else
-        {
-            if (sp == blas_base) { blas_base = 0xFFFFFFFFu; co = o; cd = d; cinv = inv_d; }
-            if (sp == 0) { cur = REF_DONE; return; }
-            sp--;
-            cur = lds_stack[sp * LP_BLOCK + tid];
-        }
+        else cur = lds_stack[sp * LP_BLOCK + tid];
     };
 
     // COUNT: how the wave's rounds were spent (work[LP_ROUND_BASE ..], MODE 0 only): refill rounds | N rounds, N steps, lanes
@@ -495,6 +494,15 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
     // (wave-uniform branch), so each instruction runs with as many lanes as possible; lanes of other phases just wait.
     for (;;)
     {
+        // lanes that have left an instance: world ray back, next reference from the TLAS part of the stack (see pop())
+        if (__ballot(active && cur == REF_EXIT))
+        {
+            if (active && cur == REF_EXIT)
+            {
+                blas_base = 0xFFFFFFFFu; co = o; cd = d; cinv = inv_d;
+                pop();
+            }
+        }
         const bool isN = active && !(cur & REF_LEAF);
         const bool isF = active && cur == REF_DONE;
         const bool isLeaf = active && (cur & REF_LEAF) && cur != REF_DONE;
@@ -608,17 +616,19 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
                     }
                     else
                     {
-                        const NodeRegs nd = geo.node(blas_base != 0xFFFFFFFFu, cur);
-                        float ld = slab_dst(co, cinv, nd.a.x, nd.a.y, nd.a.z, nd.a.w, nd.b.x, nd.b.y);
-                        float rd = slab_dst(co, cinv, nd.b.z, nd.b.w, nd.c.x, nd.c.y, nd.c.z, nd.c.w);
-                        bool left_first = ld <= rd;
-                        bool push_l = ld < best.t, push_r = rd < best.t;
-                        uint32_t near_ref = left_first ? nd.left : nd.right;
-                        uint32_t far_ref = left_first ? nd.right : nd.left;
-                        bool push_near = left_first ? push_l : push_r;
-                        bool push_far = left_first ? push_r : push_l;
-                        if (push_far) { lds_stack[sp * LP_BLOCK + tid] = far_ref; sp++; }
-                        if (push_near) cur = near_ref; else pop();
+                        const NodeRegs nd = geo.node(false, cur);
+                        float ld, rd;
+                        slab_pair(co, cinv, nd.a, nd.b, nd.c, ld, rd);
+                        // bvh_custom.wgsl:63-94 / :252-283: the nearer child (left on a tie) is visited first, the other parked;
+                        // each only if its entry distance is below the best hit so far.  near <= far, so "far is entered"
+                        // implies "near is entered" (neither is ever NaN): the far child is parked exactly when both are
+                        // entered, and a lone entered child is the near one.
+                        const bool left_first = ld <= rd;
+                        const uint32_t near_ref = left_first ? nd.left : nd.right;
+                        const uint32_t far_ref = left_first ? nd.right : nd.left;
+                        const float dn = __builtin_fminf(ld, rd), df = __builtin_fmaxf(ld, rd);
+                        if (df < best.t) { lds_stack[sp * LP_BLOCK + tid] = far_ref; sp++; }
+                        if (dn < best.t) cur = near_ref; else pop();
                     }
                 }
             }

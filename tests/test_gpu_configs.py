@@ -74,7 +74,8 @@ def test_baseline_config_at_full_size(gpu_ctx, label, name, cam_i, W, H, bounces
     ref = np.zeros((H, W, 4), np.float16)
     for t in pick_tiles(ts, W, H, fractions):
         tp = api.TileParams(tile_size=ts, tile_idx=t)
-        # the default (wide tracer + re-trace) first: counters of its own layout, image compared below
+        # the wide tracer + re-trace first: counters of its own layout, image compared below
+        gpu_ctx.set_traversal("wide")
         gpu_ctx.stats_reset(2)
         api.pathtrace_scene(gpu_ctx, res, scene, tex, 0, api.PathtraceDesc(camera_params=params, camera_transform=cam.transform, tile_params=tp))
         wst = gpu_ctx.stats()
@@ -85,7 +86,6 @@ def test_baseline_config_at_full_size(gpu_ctx, label, name, cam_i, W, H, bounces
         gpu_ctx.stats_reset(2)
         api.pathtrace_scene(gpu_ctx, res, scene, tex, 0, api.PathtraceDesc(camera_params=params, camera_transform=cam.transform, tile_params=tp))
         st = gpu_ctx.stats()
-        gpu_ctx.set_traversal("wide")
         gpu_ctx.stats_reset(0)
         assert st["wide_traversal"] == 0 and util.f16_words_differ(wide_img, tex.download()) == 0
         # a wide-node visit replaces up to three of the binary tree's (deep BLASes: about two; a sky tile that only touches the

@@ -15,6 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 REF_LEAF = 0x80000000
 REF_NONE = 0xFFFFFFFF
+REF_LEAKY = 0x40000000
+REF_INDEX = 0x3FFFFFFF
 
 
 def collapse(nodes, verts=None, idx=None, ntris=0):
@@ -66,9 +68,9 @@ def leaky_by_numpy(nodes, verts, idx):
 
 def check_collapse(nodes, verts, idx):
     """Every child box of a wide node is a box the reference's tree stores (bit for bit), every leaf of the binary tree hangs
-    under exactly one wide slot with its own box, unused slots are NaN / REF_NONE, a node holds two to four children, the
-    children pulled up came out of boxes that contain them, and the 'box does not bound its triangles' marks (per child,
-    per triangle) equal an independent numpy restatement."""
+    under exactly one wide slot with its own box, unused slots are NaN / REF_NONE, a node holds two to four children, and
+    the 'box does not bound its triangles' marks (bit 30 of a child reference, bit 1 of a triangle's flags) equal an
+    independent numpy restatement."""
     ntris = len(idx) // 3
     wide, root, flags = collapse(nodes, verts, idx)
     leaky_tri, leaky_node = leaky_by_numpy(nodes, verts, idx)
@@ -95,24 +97,24 @@ def check_collapse(nodes, verts, idx):
         visited.add(w)
         refs = wide[w, 24:28]
         used = refs != REF_NONE
-        mask = int(wide[w, 28])
-        assert 2 <= used.sum() <= 4 and np.all(wide[w, 29:32] == 0) and mask < 16
+        assert 2 <= used.sum() <= 4 and np.all(wide[w, 28:32] == 0)
         for k in range(4):
             lo = tuple(f32[w, [0 + k, 4 + k, 8 + k]].tolist())
             hi = tuple(f32[w, [12 + k, 16 + k, 20 + k]].tolist())
             if not used[k]:
-                assert all(np.isnan(v) for v in lo + hi) and not (mask >> k) & 1
+                assert all(np.isnan(v) for v in lo + hi)
                 continue
             r = int(refs[k])
+            leaky = bool(r & REF_LEAKY)
             if r & REF_LEAF:
-                n = leaf_of[r & ~REF_LEAF]
+                n = leaf_of[r & REF_INDEX]
                 assert box(nodes[n]) == (lo, hi)
-                assert bool((mask >> k) & 1) == bool(leaky_node[n])
-                seen_leaves.append(r & ~REF_LEAF)
+                assert leaky == bool(leaky_node[n])
+                seen_leaves.append(r & REF_INDEX)
             else:
                 cands = internal[(lo, hi)]                       # a box of the reference's tree, bit for bit
-                assert bool((mask >> k) & 1) in {bool(leaky_node[n]) for n in cands}
-                stack.append(r)
+                assert leaky in {bool(leaky_node[n]) for n in cands}
+                stack.append(r & REF_INDEX)
     assert len(visited) == len(wide)
     assert sorted(seen_leaves) == sorted(leaf_of)
     return len(wide), int(leaky_tri.sum())
@@ -256,28 +258,39 @@ def test_exact_ties_are_flagged_and_the_pipeline_stays_exact(gpu_ctx):
     assert np.array_equal(w[3][okh], o[3][okh]) and np.array_equal(w[4][okh], o[4][okh])
     assert np.array_equal(w[1][okh].view(np.uint32), o[1][okh].view(np.uint32))
     cam = cams[0]
-    for ptype in (0, 1):
-        gpu_ctx.stats_reset(0)
-        got = util.gpu_accumulate(gpu_ctx, scene, cam, 96, 96, 2, 2, max_bounces=5, ptype=ptype)
-        st = gpu_ctx.stats()
-        ref = util.oracle_accumulate(scene, cam, 96, 96, 2, 2, max_bounces=5, ptype=ptype)
-        assert util.f16_words_differ(got, ref) == 0
-        assert st["wide_traversal"] == 1 and st["wide_retraced"] > 0.5 * st["wide_queries"]
+    gpu_ctx.set_traversal("wide")
+    try:
+        for ptype in (0, 1):
+            gpu_ctx.stats_reset(0)
+            got = util.gpu_accumulate(gpu_ctx, scene, cam, 96, 96, 2, 2, max_bounces=5, ptype=ptype)
+            st = gpu_ctx.stats()
+            ref = util.oracle_accumulate(scene, cam, 96, 96, 2, 2, max_bounces=5, ptype=ptype)
+            assert util.f16_words_differ(got, ref) == 0
+            assert st["wide_traversal"] == 1 and st["wide_retraced"] > 0.5 * st["wide_queries"]
+    finally:
+        gpu_ctx.set_traversal("binary")
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("ptype", [0, 1, 3])
 def test_pipeline_counts_and_reports_the_fallback(gpu_ctx, ptype):
-    """The default pipeline on a scene traversed from global memory runs the wide tracer (stats say so), re-traces a small
-    share of the queries, and renders the oracle's image bit for bit."""
+    """With the wide tracer selected, the pipeline on a scene traversed from global memory runs it (stats say so), re-traces a
+    small share of the queries, and renders the oracle's image bit for bit; the default (binary) renders the same image."""
     scene, cams = util.load_scene("bistro_class_small", gpu_ctx)
     cam = cams[0]
     W, H = 160, 96
     gpu_ctx.stats_reset(0)
-    got = util.gpu_accumulate(gpu_ctx, scene, cam, W, H, 2, 3, max_bounces=6, ptype=ptype)
-    st = gpu_ctx.stats()
+    default = util.gpu_accumulate(gpu_ctx, scene, cam, W, H, 2, 3, max_bounces=6, ptype=ptype)
+    assert gpu_ctx.stats()["wide_traversal"] == 0 and gpu_ctx.stats()["wide_queries"] == 0
+    gpu_ctx.set_traversal("wide")
+    try:
+        gpu_ctx.stats_reset(0)
+        got = util.gpu_accumulate(gpu_ctx, scene, cam, W, H, 2, 3, max_bounces=6, ptype=ptype)
+        st = gpu_ctx.stats()
+    finally:
+        gpu_ctx.set_traversal("binary")
     ref = util.oracle_accumulate(scene, cam, W, H, 2, 3, max_bounces=6, ptype=ptype)
-    assert util.f16_words_differ(got, ref) == 0
+    assert util.f16_words_differ(got, ref) == 0 and util.f16_words_differ(default, ref) == 0
     assert st["wide_traversal"] == 1 and st["wide_queries"] > 0
     rate = st["wide_retraced"] / st["wide_queries"]
     print(f"type {ptype}: {st['wide_queries']} wide queries, {st['wide_retraced']} re-traced ({100 * rate:.3f} %)")
@@ -312,7 +325,7 @@ def test_device_side_verification_finds_no_uncertified_difference(built):
     """LUPIN_VERIFY_WIDE=1: every closest-hit query of real path-traced frames, binary vs wide on the device.  No unflagged
     ray may differ; the raw count (flags ignored) shows what the certificate is there for."""
     import json
-    out = _child(VERIFY % ROOT, {"LUPIN_VERIFY_WIDE": "1"})
+    out = _child(VERIFY % ROOT, {"LUPIN_VERIFY_WIDE": "1", "LUPIN_TRAVERSAL": "wide"})
     res = json.loads([l for l in out.splitlines() if l.startswith("RESULT ")][0][7:])
     for name, r in res.items():
         print(name, r)
@@ -322,8 +335,8 @@ def test_device_side_verification_finds_no_uncertified_difference(built):
 
 
 @pytest.mark.gpu
-def test_binary_switch_renders_the_same_image(built):
-    """LUPIN_TRAVERSAL=binary (the reference's order only) and the default give identical images and the switch is honoured."""
+def test_traversal_switch_renders_the_same_image(built):
+    """LUPIN_TRAVERSAL=wide and the default (the reference's order only) give identical images and the switch is honoured."""
     code = r"""
 import sys, hashlib
 sys.path.insert(0, %r)
@@ -336,7 +349,7 @@ img = util.gpu_accumulate(ctx, scene, cams[0], 200, 120, 2, 3, max_bounces=6, pt
 st = ctx.stats()
 print("RESULT", hashlib.sha256(img.tobytes()).hexdigest(), st["wide_traversal"], st["wide_queries"])
 """ % ROOT
-    a = [l for l in _child(code, {}).splitlines() if l.startswith("RESULT")][0].split()
-    b = [l for l in _child(code, {"LUPIN_TRAVERSAL": "binary"}).splitlines() if l.startswith("RESULT")][0].split()
+    a = [l for l in _child(code, {"LUPIN_TRAVERSAL": "wide"}).splitlines() if l.startswith("RESULT")][0].split()
+    b = [l for l in _child(code, {}).splitlines() if l.startswith("RESULT")][0].split()
     assert a[1] == b[1]
     assert a[2] == "1" and int(a[3]) > 0 and b[2] == "0" and int(b[3]) == 0
