@@ -93,11 +93,14 @@ def own_layout_bytes(kst, mode=0):
 
 def pmc_record(workload_key):
     """HBM traffic and L2 hit rate per kernel from the committed rocprofv3 --pmc passes of this workload (profiles/)."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if not os.path.exists(path):
-        return {}
-    with open(path) as f:
-        return json.load(f).get(workload_key, {})
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):   # the newest committed passes that cover this workload
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as f:
+                rec = json.load(f).get(workload_key)
+            if rec:
+                return dict(rec, source=name)
+    return {}
 
 
 def request_ceiling():
@@ -166,11 +169,14 @@ def measure_single_gpu(api, ctx, scene, cam, width, height, bounces, spp, steps,
         pmc = pmc_record(workload_key)
         traffic_per_unit = pmc.get("hbm_bytes_per_unit", {}).get("k_extend")
         rec["roofline"] = {
-            "bound": "hbm", "kernel": "k_extend_persistent" if not scene_is_lds_resident(scene) else "k_extend",
+            # a scene staged in LDS (Cornell box) is served on-chip: its tracer is bound by LDS reads / instruction issue, and a
+            # fraction of the HBM peak says nothing about it (round 2 printed 0.98 there, 1.27 of the measured peak)
+            "bound": "lds/issue" if scene_is_lds_resident(scene) else "hbm",
+            "kernel": "k_extend_persistent" if not scene_is_lds_resident(scene) else "k_extend",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "peak_measured": peak_measured, "frac_of_measured_peak": achieved / peak_measured if peak_measured else None,
             "traffic": traffic_per_unit * units_per_launch if traffic_per_unit else None,
-            "traffic_bytes_per_unit": traffic_per_unit, "l2_hit": pmc.get("l2_hit", {}).get("k_extend"),
+            "traffic_bytes_per_unit": traffic_per_unit, "l2_hit": pmc.get("l2_hit", {}).get("k_extend"), "pmc_source": pmc.get("source"),
             "bytes_per_unit": own["bytes_per_unit"], "bytes_per_unit_terms": {k: own[k] for k in own if k != "bytes_per_unit"},
             "units_per_launch": units_per_launch, "avg_launch_us": avg_s * 1e6, "launches_timed": launches,
             "share_of_frame_time": kst["extend_ms"] / kst["total_ms"] if kst["total_ms"] else None,
@@ -190,7 +196,8 @@ def measure_single_gpu(api, ctx, scene, cam, width, height, bounces, spp, steps,
                 "definition": "TCP_TCC_READ_REQ per path-bounce (PMC pass in profiles/) x units per launch / launch time, against the rate of "
                               "independent random 64- / 128-byte record fetches measured by tools/calib/gather_probe on this chip"}
         if scene_is_lds_resident(scene):
-            rec["roofline"]["note"] = "geometry is staged in LDS (scene < 24 KB): requests are served on-chip, HBM is not the limiter here"
+            rec["roofline"]["note"] = ("geometry is staged in LDS (scene < 24 KB): requests are served on-chip; `achieved` / `frac` are the "
+                                       "requested bytes against the HBM peak for reference only, not a bound")
     return rec, res, params
 
 
@@ -305,6 +312,7 @@ def main():
     ap.add_argument("--bounces", type=int, default=16)
     ap.add_argument("--integrator", default="Standard", choices=["Standard", "MIS", "Naive", "Direct"], help="pathtrace type (the headline is Standard)")
     ap.add_argument("--tile-size", type=int, default=8, help="tile edge in 4-px workgroups for multi-GPU sharding")
+    ap.add_argument("--gather", default="root", choices=["root", "all"], help="N > 1 readback: tiles to rank 0 (ncclSend / ncclRecv) or to every rank (ncclAllGather)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (cpu_baseline, parity, accuracy)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel passes (roofline = null)")
     ap.add_argument("--no-secondary", action="store_true", help="skip BASELINE configs 2 and 3")
@@ -355,7 +363,10 @@ def main():
 
     def gather():
         out.flip()   # front = last rendered frame
-        comm.gather_framebuffer(out.front(), args.tile_size)
+        if args.gather == "root":
+            comm.gather_framebuffer_to(out.front(), args.tile_size, 0)   # the readback: rank 0 receives the other ranks' tiles
+        else:
+            comm.gather_framebuffer(out.front(), args.tile_size)         # every rank ends up with the whole frame
         out.flip()
 
     def full_sync():
@@ -376,12 +387,18 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    render_s = gather_s = None
     if comm is not None:
+        ctx.sync()                         # this rank's frames are done (the gather below waits for them anyway)
+        render_s = time.perf_counter() - t0
         gather()
+        ctx.sync()
+        gather_s = time.perf_counter() - t0 - render_s
     full_sync()
     elapsed = time.perf_counter() - t0
 
     st = ctx.stats()
+    lanes_used = int(st["frames_in_flight"])   # what the library used for this scene, not what an environment variable might say
     total_units, total_paths = float(st["path_bounces"]), float(st["paths"])
     rank_units = total_units
     if comm is not None:
@@ -389,8 +406,15 @@ def main():
         elapsed = float(comm.allreduce([elapsed], "max")[0])
         lo = float(-comm.allreduce([-rank_units], "max")[0])
         hi = float(comm.allreduce([rank_units], "max")[0])
+        # per-phase times of the ranks (diagnosis of a scaling curve: is it the slowest rank's rendering or the exchange?)
+        rmax, gmax = (float(v) for v in comm.allreduce([render_s, gather_s], "max"))
+        rmin, gmin = (float(-v) for v in comm.allreduce([-render_s, -gather_s], "max"))
+        phases = {"render_ms_min_max": [rmin * 1e3, rmax * 1e3], "gather_ms_min_max": [gmin * 1e3, gmax * 1e3],
+                  "gather": "ncclSend/ncclRecv to rank 0" if args.gather == "root" else "ncclAllGather",
+                  "gather_payload_bytes": W * H * 8}
     else:
         lo = hi = rank_units
+        phases = None
 
     extras = {}
     if rank == 0 and world == 1 and comm is None:
@@ -405,11 +429,11 @@ def main():
             "config": {"workload": f"{args.scene} {W}x{H}, {args.bounces} bounces, {args.spp} spp per step, {args.integrator} integrator, software BVH "
                                    f"(BASELINE configs[4] frame; stand-in scene for bistroexterior, SURVEY 8d)",
                        "scene": getattr(scene, "stats", None), "samples_per_pixel_per_step": args.spp,
-                       "spp_total_timed": args.spp * args.steps, "frames_in_flight": int(os.environ.get("LUPIN_LANES", "3")),
+                       "spp_total_timed": args.spp * args.steps, "frames_in_flight": lanes_used, "traversal": "wide" if st["wide_traversal"] else "binary",
                        "scene_load_and_build_s": load_s,
                        "sharding": "single dispatch" if comm is None else
-                                   f"same frame tile-sharded over {world} ranks, tile {args.tile_size * 4}px round-robin, RCCL all-gather at readback (C ABI)",
-                       "rank_path_bounces_min_max": [lo, hi]},
+                                   f"same frame tile-sharded over {world} ranks, tile {args.tile_size * 4}px round-robin, RCCL gather at readback (C ABI, --gather {args.gather})",
+                       "rank_path_bounces_min_max": [lo, hi], "rank_phases": phases},
             "Mpaths_per_s": total_paths / elapsed / 1e6,
             "path_bounces": total_units, "timed_seconds": elapsed,
             "hip_runtime": info,

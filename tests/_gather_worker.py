@@ -50,16 +50,47 @@ for k in range(4):   # frames, a gather in the middle, more frames: the sequence
                               ts, 0, 1)
     if k == 1:
         comm.gather_framebuffer(out.front(), ts)
+    if k == 2:
+        comm.gather_framebuffer_to(out.front(), ts, 0)   # the readback form (world 1: pack only; the call must still be well-formed)
     out.flip()
 out.flip()
+comm.gather_framebuffer_to(out.front(), ts, 0)
 comm.gather_framebuffer(out.front(), ts)
 got = out.front().download()
 ref = util.gpu_accumulate(ctx, scene, cam, W, H, frames=4, spp=2, max_bounces=5)
 assert util.f16_words_differ(got, ref) == 0
 assert float(comm.allreduce([3.0, 4.0], "sum")[1]) == 4.0 and float(comm.allreduce([5.0], "max")[0]) == 5.0
+try:
+    comm.gather_framebuffer_to(out.front(), ts, 1)   # no such rank
+    raise SystemExit("root out of range was accepted")
+except api.LupinError:
+    pass
 comm.barrier()
 comm.close()
 print("GATHER OK")
+
+# 2b. f32 accumulation mode: tiles that arrive through an unpack must refresh the f32 accumulator too (advisor, round 2)
+import numpy as np   # noqa: E402
+ctx.set_accumulation_mode(1)
+try:
+    frames32 = []
+    for r in range(world):
+        t = api.Texture(ctx, W, H)
+        api.pathtrace_scene_tiles(ctx, res, scene, t, 0, desc, ts, r, world)
+        frames32.append(t)
+        api.pack_tiles(ctx, t, ts, r, world, gathered.device_ptr() + r * capacity * 8)
+    for r in range(world):
+        api.unpack_gathered_tiles(ctx, frames32[r], ts, r, world, gathered.device_ptr(), capacity)
+        f32 = frames32[r].download_f32()
+        f16 = frames32[r].download()
+        assert util.f16_words_differ(f16, want) == 0
+        # every texel of the accumulator is the value its f16 view shows: own tiles exactly rounded, foreign tiles widened
+        assert np.array_equal(f32.astype(np.float16).view(np.uint16)[..., :3], f16.view(np.uint16)[..., :3]) or \
+            np.allclose(f32[..., :3], f16[..., :3].astype(np.float32), rtol=2e-3, atol=1e-6)
+        assert np.all(f32[..., :3].sum(axis=2)[want[..., :3].astype(np.float32).sum(axis=2) > 0] > 0)   # no zero / stale holes
+finally:
+    ctx.set_accumulation_mode(0)
+print("F32 UNPACK OK")
 
 # 4. the one-process-N-contexts layout (lupin_hip_comm_init_all + lupin_hip_gather_framebuffer_all, one RCCL group) with the
 #    one device this box has: same frames, same result
