@@ -84,10 +84,10 @@ try:
         f32 = frames32[r].download_f32()
         f16 = frames32[r].download()
         assert util.f16_words_differ(f16, want) == 0
-        # every texel of the accumulator is the value its f16 view shows: own tiles exactly rounded, foreign tiles widened
-        assert np.array_equal(f32.astype(np.float16).view(np.uint16)[..., :3], f16.view(np.uint16)[..., :3]) or \
-            np.allclose(f32[..., :3], f16[..., :3].astype(np.float32), rtol=2e-3, atol=1e-6)
-        assert np.all(f32[..., :3].sum(axis=2)[want[..., :3].astype(np.float32).sum(axis=2) > 0] > 0)   # no zero / stale holes
+        # every texel of the accumulator is what its f16 view shows (own tiles: the unrounded value, within one f16 ulp; tiles of
+        # another rank: the f16 texel widened) -- in particular no zero or stale holes where other ranks rendered
+        assert np.allclose(f32[..., :3], f16[..., :3].astype(np.float32), rtol=1.5e-3, atol=1e-7)
+        assert np.all(f32[..., 3] == 1.0)
 finally:
     ctx.set_accumulation_mode(0)
 print("F32 UNPACK OK")
