@@ -334,6 +334,18 @@ int lupin_hip_sync(LupinContext *ctx);
 #define LUPIN_STORE_ROUND_NEAREST_EVEN 1
 int lupin_hip_set_f16_store_rounding(LupinContext *ctx, int mode);
 
+/* Frames per wavefront.  pathtrace_scene is enqueue-and-return like the reference's queue.submit
+ * (renderer.rs:841); consecutive calls that differ only in camera and accum_counter and chain their textures (each call's
+ * prev_frame is the previous call's render_target -- the reference's front / back / flip loop) are recorded and executed
+ * as ONE wavefront of up to `frames` calls: the stage kernels see `frames` times as many paths per launch, the resolve
+ * applies the calls' blends per pixel in call order.  Same texels as one wavefront per call, bit for bit.  A batch runs
+ * when it is full or as soon as anything needs its result: lupin_hip_sync, texture download / upload / copy, tonemap, pack /
+ * gather, falsecolor / debug calls, statistics, a call that cannot join (other scene / integrator / size / parameters /
+ * texture chain), a mode setter, teardown of any object.  An error of a recorded call is reported by the call that runs the
+ * batch.  frames in [1, 8], default 4 (LUPIN_BATCH); 1 = every call is its own wavefront.  f32 accumulation, kernel timing
+ * and work counting run unbatched. */
+int lupin_hip_set_batch_frames(LupinContext *ctx, uint32_t frames);
+
 /* Which hierarchy the persistent tracer walks on scenes traversed from global memory (DESIGN.md 5 "Wide traversal").
  * BINARY (default): the reference's own visiting order for every query.  WIDE: the four-wide collapse of the reference's
  * trees with an exactness certificate; queries it cannot certify are re-traced in the reference's order

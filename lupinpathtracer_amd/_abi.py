@@ -160,6 +160,7 @@ SYMBOLS = [
     ("lupin_hip_set_f16_store_rounding", C.c_int, [_P, C.c_int]),
     ("lupin_hip_set_accumulation_mode", C.c_int, [_P, C.c_int]),
     ("lupin_hip_set_traversal", C.c_int, [_P, C.c_int]),
+    ("lupin_hip_set_batch_frames", C.c_int, [_P, _U32]),
     ("lupin_hip_reserve_path_state", C.c_int, [_P, C.c_uint64, _U32, _U32]),
     ("lupin_hip_texture_download_rgba32f", C.c_int, [_P, _P]),
     ("lupin_hip_measure_copy_bandwidth", C.c_int, [_P, C.c_uint64, _U32, C.POINTER(C.c_double)]),

@@ -185,6 +185,10 @@ class Context:
         """Allocate the path state of every frame in flight now instead of at each lane's first pathtrace call."""
         check(lib().lupin_hip_reserve_path_state(self.handle, int(pixels), int(max_bounces), int(samples_per_pixel)))
 
+    def set_batch_frames(self, frames):
+        """Frames per wavefront: how many consecutive, chained pathtrace_scene calls run as one wavefront (1..8, default 4)."""
+        check(lib().lupin_hip_set_batch_frames(self.handle, int(frames)))
+
     def set_traversal(self, mode):
         """"binary" (default: the reference's visiting order) or "wide" (four-wide hierarchy + exactness certificate + re-trace)."""
         check(lib().lupin_hip_set_traversal(self.handle, {"binary": 0, "wide": 1}[mode]))

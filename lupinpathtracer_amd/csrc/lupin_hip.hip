@@ -101,6 +101,15 @@ struct LupinContext
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_extend, ev_shade, ev_total;
     std::vector<hipEvent_t> ev_pool;
     uint64_t extend_launches = 0;
+    // Frames per wavefront: pathtrace_scene calls that differ only in camera / accum_counter and chain their textures
+    // (each call's prev_frame is the previous call's render_target) are recorded here and run as ONE wavefront when the batch is
+    // full or anything needs their result (flush_pending: sync, texture reads and writes, another kind of call, teardown).
+    struct PendingFrame { FrameParams fp; LupinTexture *target; const LupinTexture *prev; };
+    std::vector<PendingFrame> pending;
+    const LupinScene *pending_scene = nullptr;
+    uint32_t pending_type = 0;
+    uint32_t batch_frames = 4;             // LUPIN_BATCH=1..8: calls per wavefront (1 = every call is its own wavefront)
+    bool in_flush = false;
     int last_lanes = 0;                    // frames in flight the latest pathtrace call could use (reported by lupin_hip_stats_get)
     bool last_wide = false;                // ... and whether it ran the four-wide tracer
 };
@@ -723,13 +732,18 @@ static hipError_t enqueue_wavefront(LupinContext *ctx, Lane *ln, const LupinScen
     return hipSuccess;
 }
 
+static int flush_pending(LupinContext *ctx);
+
 // The resolves form a chain (each waits for the previous call's), so the latest call's event covers all lanes' texture writes.
+// Every reader / writer of a texture on the primary stream comes through here (or through sync_all): recorded calls run first.
 static void join_primary(LupinContext *ctx)
 {
+    flush_pending(ctx);
     if (ctx->last_lane > 0) hipStreamWaitEvent(ctx->stream, ctx->lanes[ctx->last_lane].done, 0);
 }
 static hipError_t sync_all(LupinContext *ctx)
 {
+    if (flush_pending(ctx) != LUPIN_OK) return hipErrorUnknown;
     hipError_t e = hipSuccess;
     for (int k = 0; k < LP_MAX_LANES && e == hipSuccess; k++)
         if (ctx->lanes[k].stream) e = hipStreamSynchronize(ctx->lanes[k].stream);
@@ -815,7 +829,7 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
         Lane &ln = ctx->lanes[k];
         e = hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ln.done, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipMalloc((void **)&ln.d_fp, sizeof(FrameParams));
+        if (e == hipSuccess) e = hipMalloc((void **)&ln.d_fp, LP_MAX_BATCH * sizeof(FrameParams));
         if (e == hipSuccess) e = hipMalloc((void **)&ln.stat_counters, 2 * LP_SHARDS * sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMemsetAsync(ln.stat_counters, 0, 2 * LP_SHARDS * sizeof(unsigned long long), ln.stream);
         if (e == hipSuccess) e = hipMalloc((void **)&ln.work_counters, LP_WORK_WORDS * sizeof(unsigned long long));
@@ -863,6 +877,7 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
     if (shd && strcmp(shd, "simple") == 0) ctx->persistent_shadow = false;
     const char *ns = getenv("LUPIN_NODE_STEPS");
     if (ns) ctx->node_steps = (uint32_t)std::min(16, std::max(1, atoi(ns)));
+    if (const char *bf = getenv("LUPIN_BATCH")) ctx->batch_frames = (uint32_t)std::min((int)LP_MAX_BATCH, std::max(1, atoi(bf)));
     if (const char *tv = getenv("LUPIN_TRAVERSAL")) ctx->wide_traversal = strcmp(tv, "wide") == 0;
     if (const char *ws = getenv("LUPIN_WIDE_STACK")) ctx->wide_stack_pairs = (uint32_t)std::min(64, std::max(4, atoi(ws)));
     if (const char *vw = getenv("LUPIN_VERIFY_WIDE")) ctx->verify_wide = atoi(vw) != 0;
@@ -913,14 +928,26 @@ int lupin_hip_sync(LupinContext *ctx)
 int lupin_hip_set_f16_store_rounding(LupinContext *ctx, int mode)
 {
     CTX_ALIVE_TRY(ctx);
+    if (ctx) { int frc = flush_pending(ctx); if (frc != LUPIN_OK) return frc; }   // calls recorded so far ran under the old setting
     if (!ctx || (mode != 0 && mode != 1)) return fail(LUPIN_ERR_INVALID_ARGUMENT, "mode must be 0 (toward zero) or 1 (nearest even)");
     ctx->store_rounding = mode;
+    return LUPIN_OK;
+}
+
+int lupin_hip_set_batch_frames(LupinContext *ctx, uint32_t frames)
+{
+    CTX_ALIVE_TRY(ctx);
+    if (!ctx || frames < 1 || frames > LP_MAX_BATCH) return fail(LUPIN_ERR_INVALID_ARGUMENT, "frames per wavefront must be in [1, 8]");
+    int frc = flush_pending(ctx);
+    if (frc != LUPIN_OK) return frc;
+    ctx->batch_frames = frames;
     return LUPIN_OK;
 }
 
 int lupin_hip_set_traversal(LupinContext *ctx, int mode)
 {
     CTX_ALIVE_TRY(ctx);
+    if (ctx) { int frc = flush_pending(ctx); if (frc != LUPIN_OK) return frc; }   // calls recorded so far ran under the old setting
     if (!ctx || (mode != LUPIN_TRAVERSAL_WIDE && mode != LUPIN_TRAVERSAL_BINARY)) return fail(LUPIN_ERR_INVALID_ARGUMENT, "unknown traversal mode");
     ctx->wide_traversal = mode == LUPIN_TRAVERSAL_WIDE;
     return LUPIN_OK;
@@ -929,6 +956,7 @@ int lupin_hip_set_traversal(LupinContext *ctx, int mode)
 int lupin_hip_set_accumulation_mode(LupinContext *ctx, int mode)
 {
     CTX_ALIVE_TRY(ctx);
+    if (ctx) { int frc = flush_pending(ctx); if (frc != LUPIN_OK) return frc; }   // calls recorded so far ran under the old setting
     if (!ctx || (mode != LUPIN_ACCUM_F16_RUNNING_AVERAGE && mode != LUPIN_ACCUM_F32)) return fail(LUPIN_ERR_INVALID_ARGUMENT, "unknown accumulation mode");
     ctx->accum_mode = mode;
     return LUPIN_OK;
@@ -939,12 +967,12 @@ int lupin_hip_set_accumulation_mode(LupinContext *ctx, int mode)
 int lupin_hip_reserve_path_state(LupinContext *ctx, uint64_t pixels, uint32_t max_bounces, uint32_t samples_per_pixel)
 {
     CTX_ALIVE_TRY(ctx);
-    if (pixels == 0 || pixels > (uint64_t)QUEUE_SLOT_MASK || samples_per_pixel == 0) return fail(LUPIN_ERR_INVALID_ARGUMENT, "bad path-state reservation");
+    if (pixels == 0 || pixels * LP_MAX_BATCH > (uint64_t)QUEUE_SLOT_MASK || samples_per_pixel == 0) return fail(LUPIN_ERR_INVALID_ARGUMENT, "bad path-state reservation");
     HIP_TRY(hipSetDevice(ctx->device));
     const uint32_t iterations = samples_per_pixel * (max_bounces + 1);
     for (int k = 0; k < ctx->num_lanes; k++)
     {
-        int rc = ensure_path_buffers(ctx, &ctx->lanes[k], pixels, iterations);
+        int rc = ensure_path_buffers(ctx, &ctx->lanes[k], pixels * ctx->batch_frames, iterations);
         if (rc != LUPIN_OK) return rc;
     }
     return LUPIN_OK;
@@ -1581,7 +1609,7 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
         n64 = (uint64_t)fp.reg_w * fp.reg_h;
     }
     if (n64 == 0) return LUPIN_OK;
-    if (n64 > (uint64_t)QUEUE_SLOT_MASK) return fail(LUPIN_ERR_INVALID_ARGUMENT, "dispatch too large");   // queue entries keep two bits for the light-pdf stage
+    if (n64 * LP_MAX_BATCH > (uint64_t)QUEUE_SLOT_MASK) return fail(LUPIN_ERR_INVALID_ARGUMENT, "dispatch too large");   // queue entries keep two bits for the light-pdf stage; a wavefront holds up to LP_MAX_BATCH frames
     const uint32_t n = (uint32_t)n64;
 
     if (falsecolor_type >= 0 || debug)
@@ -1605,12 +1633,66 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
         return LUPIN_OK;
     }
 
+    // ---- record the call; run the batch when it is full or cannot grow (DESIGN 5 "Frames per wavefront") ----
+    fp.frame_slots = n;
+    fp.num_frames = 1;
+    const bool batchable = ctx->batch_frames > 1 && !ctx->timing && !ctx->counting && !ctx->verify_wide && !ctx->debug_sync &&
+                           ctx->accum_mode != LUPIN_ACCUM_F32;
+    if (!ctx->pending.empty())
+    {
+        // a call joins the batch if it differs from the batch's first call only in camera and accum_counter, and blends with
+        // what the previous call of the batch stores (or with nothing: accum_counter 0)
+        FrameParams a = ctx->pending.front().fp, b = fp;
+        for (FrameParams *q : {&a, &b})
+        {
+            memset(&q->pc.camera_transform, 0, sizeof(q->pc.camera_transform));
+            q->pc.camera_lens = q->pc.camera_film = q->pc.camera_aspect = q->pc.camera_focus = q->pc.camera_aperture = 0.0f;
+            q->pc.accum_counter = 0;
+            q->pc.flags &= ~(uint32_t)LUPIN_FLAG_CAMERA_ORTHO;
+            q->num_frames = 1;
+        }
+        const bool joins = batchable && ctx->pending_scene == scene && ctx->pending_type == pathtrace_type && memcmp(&a, &b, sizeof(a)) == 0 &&
+                           (fp.pc.accum_counter == 0 || prev == ctx->pending.back().target) && ctx->pending.size() < ctx->batch_frames;
+        if (!joins)
+        {
+            int rc = flush_pending(ctx);
+            if (rc != LUPIN_OK) return rc;
+        }
+    }
+    ctx->pending.push_back({fp, render_target, prev});
+    ctx->pending_scene = scene;
+    ctx->pending_type = pathtrace_type;
+    if (!batchable || ctx->pending.size() >= ctx->batch_frames) return flush_pending(ctx);
+    return LUPIN_OK;
+}
+
+// Runs the recorded calls as one wavefront: slot = frame * frame_slots + pixel slot, one resolve that applies the frames'
+// blends per pixel in call order.  Errors of a deferred call surface here, i.e. at the call that needed its result.
+static int flush_pending(LupinContext *ctx)
+{
+    if (ctx->pending.empty() || ctx->in_flush) return LUPIN_OK;
+    ctx->in_flush = true;
+    struct Done { LupinContext *c; ~Done() { c->pending.clear(); c->pending_scene = nullptr; c->in_flush = false; } } done{ctx};
+    HIP_TRY(hipSetDevice(ctx->device));
+    const LupinScene *scene = ctx->pending_scene;
+    const uint32_t pathtrace_type = ctx->pending_type;
+    const uint32_t K = (uint32_t)ctx->pending.size();
+    FrameParams fp = ctx->pending.front().fp;
+    fp.num_frames = K;
+    const uint32_t frame_slots = fp.frame_slots;
+    const uint32_t n = K * frame_slots;                         // slots of the wavefront
+    LupinTexture *render_target = ctx->pending.back().target;    // (f32 accumulation is never batched: K == 1 there)
+    const LupinTexture *prev = ctx->pending.front().prev;
+    const uint32_t W = fp.width, H = fp.height;
+
     // Lane choice: consecutive calls alternate so that their wavefronts overlap; per-kernel timing needs them serial.
     // Scenes traced by the persistent kernel use every lane: the middle iterations of a frame hold too few rays to fill the
     // chip and are bounded by the latency of one traversal, so more frames in flight fill it (an eighth of the 4K frame:
     // 34.1 -> 30.1 ms with 8 lanes on 8 hardware queues).  Launch-bound LDS-resident scenes are best with three.
+    // With several frames per wavefront (the default) four wavefronts in flight are enough (measured: bistro-class 4K 1 227 ->
+    // 1 248 Msamples/s from eight to four at four frames each), and the path state stays at 16 frames' worth.
     const bool lds_scene = scene->dev.geo_blob_words && ctx->lds_geometry;
-    const int lanes = (lds_scene && !ctx->lanes_from_env) ? std::min(3, ctx->num_lanes) : ctx->num_lanes;
+    const int lanes = ctx->lanes_from_env ? ctx->num_lanes : std::min(lds_scene ? 3 : (ctx->batch_frames > 1 ? 4 : LP_MAX_LANES), ctx->num_lanes);
     const int w = ctx->timing ? 0 : (int)(ctx->call_index % (uint64_t)lanes);
     ctx->call_index++;
     Lane *ln = &ctx->lanes[w];
@@ -1647,7 +1729,12 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
     }
     ctx->last_lanes = lanes;
     ctx->last_wide = sh.wblocks != 0;
-    hipLaunchKernelGGL(k_set_params, dim3(1), dim3(1), 0, st, fp, ln->d_fp);
+    for (uint32_t k = 0; k < K; k++)
+    {
+        FrameParams fk = ctx->pending[k].fp;
+        fk.num_frames = K;
+        hipLaunchKernelGGL(k_set_params, dim3(1), dim3(1), 0, st, fk, ln->d_fp + k);
+    }
     if (ctx->use_graph && !ctx->timing && !ctx->counting && !ctx->verify_wide)
     {
         // Everything between k_set_params and the resolve depends on the call only through *d_fp, so it is captured once per
@@ -1709,8 +1796,20 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
         if (prev && prev->accum32 && prev->accum32_valid) prev32 = prev->accum32;
     }
     render_target->accum32_valid = out32 != nullptr;
-    hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(LP_BLOCK), 0, st, fp, ln->pb, n,
-                       prev ? prev->data : (const __half *)nullptr, render_target->data, prev32, out32);
+    ResolveBatch rb;
+    memset(&rb, 0, sizeof(rb));
+    rb.count = K;
+    for (uint32_t k = 0; k < K; k++)
+    {
+        rb.target[k] = ctx->pending[k].target->data;
+        rb.accum_counter[k] = ctx->pending[k].fp.pc.accum_counter;
+        bool last_write = true;
+        for (uint32_t q = k + 1; q < K; q++) last_write = last_write && ctx->pending[q].target != ctx->pending[k].target;
+        if (last_write) rb.store_mask |= 1u << k;
+        if (k + 1 < K) ctx->pending[k].target->accum32_valid = false;
+    }
+    hipLaunchKernelGGL(k_resolve, dim3((frame_slots + LP_BLOCK - 1) / LP_BLOCK), dim3(LP_BLOCK), 0, st, fp, ln->pb, frame_slots, rb,
+                       prev ? prev->data : (const __half *)nullptr, prev32, out32);
     HIP_TRY(hipEventRecord(ln->done, st));
     ln->used = true;
     ctx->last_lane = w;

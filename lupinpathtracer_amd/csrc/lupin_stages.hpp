@@ -110,7 +110,21 @@ struct FrameParams
     uint32_t store_rne;          // f32 -> f16 store rounding: 0 = toward zero (reference goldens), 1 = nearest even
     uint32_t tile_px;            // 0 = rectangular dispatch
     uint32_t tiles_x, rank, world;
+    // Batched calls (DESIGN 5 "Frames per wavefront"): consecutive pathtrace_scene calls that differ only in camera and
+    // accum_counter run as ONE wavefront; slot = frame * frame_slots + pixel slot, and the stage kernels read the lane's
+    // FrameParams ARRAY: [0] for everything the batch shares, [frame] for the camera and the RNG seed.
+    uint32_t frame_slots;        // slots (pixels of the dispatch) per frame
+    uint32_t num_frames;         // frames in this wavefront (1 = a single call)
 };
+constexpr uint32_t LP_MAX_BATCH = 8;
+
+// which frame of the batch a slot belongs to, and its pixel slot inside the frame
+__device__ __forceinline__ uint32_t slot_frame(const FrameParams &fp, uint32_t slot, uint32_t &pixel_slot)
+{
+    const uint32_t frame = fp.num_frames > 1u ? slot / fp.frame_slots : 0u;
+    pixel_slot = slot - frame * fp.frame_slots;
+    return frame;
+}
 
 // ------------------------------------------------------------------------------------------------
 // Camera (compute_camera_ray, pathtracer.wgsl:505-542) -- draws 2 (jitter) + 2 (lens) numbers
@@ -205,19 +219,22 @@ __global__ void __launch_bounds__(LP_BLOCK) k_begin(const FrameParams *__restric
 {
     const FrameParams fp = *fpp;   // per-frame parameters live in device memory so that a captured graph can be replayed
     uint32_t slot = blockIdx.x * LP_BLOCK + threadIdx.x;
-    uint32_t gx = 0, gy = 0;
+    uint32_t gx = 0, gy = 0, frame = 0;
     bool live = slot < n;
     if (live)
     {
-        slot_to_pixel(fp, slot, gx, gy);
+        uint32_t pslot;
+        frame = slot_frame(fp, slot, pslot);
+        slot_to_pixel(fp, pslot, gx, gy);
         live = gx < fp.width && gy < fp.height;   // edge tiles: texels outside the image are never stored (:287)
     }
     const uint32_t shard = blockIdx.x % LP_SHARDS;
     queue_append(live, slot, pb.queue[0] + (size_t)shard * pb.shard_cap, &pb.counts[shard]);
     if (!live) return;
-    uint32_t rng = rng_seed_for(gy * fp.width + gx, fp.pc.accum_counter);
+    const FrameParams &ff = fpp[frame];   // this frame's camera and accumulation counter
+    uint32_t rng = rng_seed_for(gy * fp.width + gx, ff.pc.accum_counter);
     f3 o, d;
-    camera_ray(fp, gx, gy, rng, o, d);
+    camera_ray(ff, gx, gy, rng, o, d);
     pb.ori_rng[slot] = make_float4(o.x, o.y, o.z, __uint_as_float(rng));
     pb.dir_meta[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(META_NEXT_EMISSION));
     pb.weight[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
@@ -1088,7 +1105,7 @@ __device__ __forceinline__ bool integrate_vertex(const Geo &geo, const SceneDev 
 // one is folded into the pixel and the pixel's next camera sample started (:234-239).  `r4` is the radiance as stored (only
 // emitters change it).  Returns whether the slot still has work.
 template <int TYPE>
-__device__ __forceinline__ bool path_epilogue(const FrameParams &fp, PathBuffers &pb, uint32_t slot, PathRegs &p, uint32_t sample, bool cont,
+__device__ __forceinline__ bool path_epilogue(const FrameParams &fp, const FrameParams *fpp, PathBuffers &pb, uint32_t slot, PathRegs &p, uint32_t sample, bool cont,
                                               bool vol_dirty, float4 r4)
 {
     bool alive = false;
@@ -1113,9 +1130,10 @@ __device__ __forceinline__ bool path_epilogue(const FrameParams &fp, PathBuffers
         if (sample < fp.spp)
         {
             alive = true;
-            uint32_t gx, gy;
-            slot_to_pixel(fp, slot, gx, gy);
-            camera_ray(fp, gx, gy, p.rng, p.ori, p.dir);
+            uint32_t gx, gy, pslot;
+            const uint32_t frame = slot_frame(fp, slot, pslot);
+            slot_to_pixel(fp, pslot, gx, gy);
+            camera_ray(fpp[frame], gx, gy, p.rng, p.ori, p.dir);
             p.bounce = 0;
             p.in_medium = false;
             p.next_emission = true;
@@ -1146,7 +1164,7 @@ constexpr uint32_t QUEUE_STATE_SHIFT = 30u, QUEUE_SLOT_MASK = (1u << QUEUE_STATE
 // back and returns whether the pixel still has work (the path continues, or its next camera sample was started) or, with
 // DEFER, waits for the light-pdf stage.
 template <int TYPE, typename Geo, bool SIMPLE = false, bool DEFER = false>
-__device__ __forceinline__ int shade_path(const Geo &geo, const SceneDev &sc, uint32_t *stack, const FrameParams &fp, PathBuffers &pb,
+__device__ __forceinline__ int shade_path(const Geo &geo, const SceneDev &sc, uint32_t *stack, const FrameParams &fp, const FrameParams *fpp, PathBuffers &pb,
                                           uint32_t slot, float4 orr, float4 dm, uint32_t rng, float4 hitrec, uint32_t hit_tri)
 {
     float4 w4 = pb.weight[slot];
@@ -1222,14 +1240,14 @@ __device__ __forceinline__ int shade_path(const Geo &geo, const SceneDev &sc, ui
         if (sh.v1) { pb.sh_d1[slot] = make_float4(sh.d1.x, sh.d1.y, sh.d1.z, sh.s1); pb.sh_f1[slot] = make_float4(sh.f1.x, sh.f1.y, sh.f1.z, 0.0f); }
         return SLOT_ALIVE;
     }
-    return path_epilogue<TYPE>(fp, pb, slot, p, sample, cont, vol_dirty, r4) ? SLOT_ALIVE : SLOT_DONE;
+    return path_epilogue<TYPE>(fp, fpp, pb, slot, p, sample, cont, vol_dirty, r4) ? SLOT_ALIVE : SLOT_DONE;
 }
 
 // The light-pdf stage's share of an iteration (Standard): sample_lights_pdf for the direction k_shade chose
 // (pathtracer.wgsl:2516-2549 -> bvh_custom.wgsl:112-152), the weight update it feeds (:652-656), the weight checks,
 // Russian roulette and the loop condition (:720-729, :596).
 template <int TYPE, typename Geo>
-__device__ __forceinline__ bool light_pdf_path(const Geo &geo, const SceneDev &sc, uint32_t *stack, const FrameParams &fp, PathBuffers &pb, uint32_t slot)
+__device__ __forceinline__ bool light_pdf_path(const Geo &geo, const SceneDev &sc, uint32_t *stack, const FrameParams &fp, const FrameParams *fpp, PathBuffers &pb, uint32_t slot)
 {
     const float4 orr = pb.ori_rng[slot], dm = pb.dir_meta[slot], w4 = pb.weight[slot], pd = pb.sh_f0[slot];
     const uint32_t meta = __float_as_uint(dm.w);
@@ -1255,7 +1273,7 @@ __device__ __forceinline__ bool light_pdf_path(const Geo &geo, const SceneDev &s
     float4 r4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (!cont) r4 = pb.radiance[slot];   // a finished path is folded into the pixel
     p.radiance = mk3(r4.x, r4.y, r4.z);
-    return path_epilogue<TYPE>(fp, pb, slot, p, sample, cont, false, r4);
+    return path_epilogue<TYPE>(fp, fpp, pb, slot, p, sample, cont, false, r4);
 }
 
 // Scenes with several material families: before k_shade, each window of LP_SORT_WINDOW queue entries is counting-sorted in place
@@ -1380,7 +1398,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(TYPE == 1 ? (DEFER ? LP_MIS_D
     if (mine)
     {
         const float4 orr = pb.ori_rng[slot];
-        state = shade_path<TYPE, typename GeoOf<LDSGEO>::type, SIMPLE, DEFER>(geo, sc, lds_stack, fp, pb, slot, orr, pb.dir_meta[slot], __float_as_uint(orr.w), pb.hit[slot], pb.hit_tri[slot]);
+        state = shade_path<TYPE, typename GeoOf<LDSGEO>::type, SIMPLE, DEFER>(geo, sc, lds_stack, fp, fpp, pb, slot, orr, pb.dir_meta[slot], __float_as_uint(orr.w), pb.hit[slot], pb.hit_tri[slot]);
     }
     if (i == 0 && iter == 0) shard_stats[shard * 2 + 1] += (unsigned long long)count * fp.spp;
     if (TYPE == LUPIN_PATHTRACE_MIS || TYPE == LUPIN_PATHTRACE_DIRECT) return;   // k_shadow appends
@@ -1429,7 +1447,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LP_LIGHT_PDF_WAVES, 8))) __la
     if (threadIdx.x < total)
     {
         const uint32_t w = waiting[threadIdx.x];
-        if (light_pdf_path<TYPE, typename GeoOf<LDSGEO>::type>(geo, sc, lds_stack, fp, pb, entry_slot[w])) verdict[w] = 1u;
+        if (light_pdf_path<TYPE, typename GeoOf<LDSGEO>::type>(geo, sc, lds_stack, fp, fpp, pb, entry_slot[w])) verdict[w] = 1u;
     }
     __syncthreads();
     const bool alive = state == (uint32_t)SLOT_ALIVE || (waits && verdict[threadIdx.x] != 0u);
@@ -1582,10 +1600,11 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launc
             {
                 alive = true;
                 uint32_t rng = __float_as_uint(pb.ori_rng[slot].w);
-                uint32_t gx, gy;
-                slot_to_pixel(fp, slot, gx, gy);
+                uint32_t gx, gy, pslot;
+                const uint32_t frame = slot_frame(fp, slot, pslot);
+                slot_to_pixel(fp, pslot, gx, gy);
                 f3 o, d;
-                camera_ray(fp, gx, gy, rng, o, d);
+                camera_ray(fpp[frame], gx, gy, rng, o, d);
                 pb.weight[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
                 pb.radiance[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 pb.next_hit[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(HIT_MISS));
@@ -1621,28 +1640,49 @@ __device__ __forceinline__ f3 load_rgb16f(const __half *tex, size_t pixel)
     const uint2 w = reinterpret_cast<const uint2 *>(tex)[pixel];
     return mk3(half_bits_to_float(w.x & 0xFFFFu), half_bits_to_float(w.x >> 16), half_bits_to_float(w.y & 0xFFFFu));
 }
-__global__ void __launch_bounds__(LP_BLOCK) k_resolve(FrameParams fp, PathBuffers pb, uint32_t n,
-                                                      const __half *prev, __half *out, const float4 *prev32, float4 *out32)
+// The frames of a batch, as the resolve sees them: where each one's result goes, which of those stores survive (a texture
+// written again by a later frame of the batch keeps only the later value), and the blend weights' counters.
+struct ResolveBatch
+{
+    __half *target[LP_MAX_BATCH];
+    uint32_t accum_counter[LP_MAX_BATCH];
+    uint32_t store_mask;          // bit k: frame k's value is the last one written to its texture
+    uint32_t count;
+};
+__global__ void __launch_bounds__(LP_BLOCK) k_resolve(FrameParams fp, PathBuffers pb, uint32_t n, ResolveBatch rb,
+                                                      const __half *prev, const float4 *prev32, float4 *out32)
 {
     uint32_t slot = blockIdx.x * LP_BLOCK + threadIdx.x;
-    if (slot >= n) return;
+    if (slot >= n) return;   // n = slots per frame
     uint32_t gx, gy;
     slot_to_pixel(fp, slot, gx, gy);
     if (gx >= fp.width || gy >= fp.height) return;
-    float4 c4 = pb.color[slot];
-    float spp = (float)fp.spp;
-    f3 c = mk3(maxf(c4.x / spp, 0.0f), maxf(c4.y / spp, 0.0f), maxf(c4.z / spp, 0.0f));
     const size_t px = (size_t)gy * fp.width + gx;
-    if (fp.pc.accum_counter != 0)
+    const float spp = (float)fp.spp;
+    const bool rne = fp.store_rne != 0;
+    f3 running = splat(0.0f);   // the value frame k blends with: prev_frame of the first call, then what the previous frame STORED
+    bool have_prev = false;
+    for (uint32_t k = 0; k < rb.count; k++)
     {
-        float w = 1.0f / (float)fp.pc.accum_counter;
-        f3 pc;
-        if (prev32) { const float4 p = prev32[px]; pc = mk3(p.x, p.y, p.z); }
-        else pc = load_rgb16f(prev, px);
-        c = mk3(maxf(pc.x * (1.0f - w) + c.x * w, 0.0f), maxf(pc.y * (1.0f - w) + c.y * w, 0.0f), maxf(pc.z * (1.0f - w) + c.z * w, 0.0f));
+        const float4 c4 = pb.color[(size_t)k * fp.frame_slots + slot];
+        f3 c = mk3(maxf(c4.x / spp, 0.0f), maxf(c4.y / spp, 0.0f), maxf(c4.z / spp, 0.0f));
+        if (rb.accum_counter[k] != 0)
+        {
+            const float w = 1.0f / (float)rb.accum_counter[k];
+            f3 pc = running;
+            if (!have_prev)
+            {
+                if (prev32) { const float4 p = prev32[px]; pc = mk3(p.x, p.y, p.z); }
+                else pc = load_rgb16f(prev, px);
+            }
+            c = mk3(maxf(pc.x * (1.0f - w) + c.x * w, 0.0f), maxf(pc.y * (1.0f - w) + c.y * w, 0.0f), maxf(pc.z * (1.0f - w) + c.z * w, 0.0f));
+        }
+        if (out32) out32[px] = make_float4(c.x, c.y, c.z, 1.0f);   // f32 accumulation is never batched: count == 1
+        if (rb.store_mask & (1u << k)) store_rgba16f(rb.target[k], px, c, rne);
+        // the next frame of the batch reads this texel back as Rgba16Float (pathtracer.wgsl:279-285): round it exactly as the store does
+        running = mk3(half_bits_to_float(f16_bits(c.x, rne)), half_bits_to_float(f16_bits(c.y, rne)), half_bits_to_float(f16_bits(c.z, rne)));
+        have_prev = true;
     }
-    if (out32) out32[px] = make_float4(c.x, c.y, c.z, 1.0f);
-    store_rgba16f(out, px, c, fp.store_rne != 0);
 }
 
 // device-to-device copy: the measured HBM peak bench.py reports next to the nominal one

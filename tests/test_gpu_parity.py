@@ -136,6 +136,65 @@ def test_overlapped_frames_keep_accumulation_order(gpu_ctx):
     assert util.f16_words_differ(out.front().download(), want) == 0
 
 
+@pytest.mark.parametrize("name,ptype", [("cornellbox_builtin", 0), ("materials4", 1), ("bistro_class_small", 0), ("bistro_class_small", 3)])
+def test_frames_per_wavefront_equal_one_call_per_wavefront(gpu_ctx, name, ptype):
+    """lupin_hip_set_batch_frames: consecutive chained calls run as ONE wavefront.  With a camera that moves every frame, an
+    accumulation that restarts in the middle (accum_counter back to 0), a tile-set call and a broken texture chain thrown in,
+    eight frames per wavefront must store exactly what one call per wavefront stores -- and that is the oracle's image."""
+    scene, cams = util.load_scene(name, gpu_ctx)
+    cam = cams[1 % len(cams)] if name == "materials4" else cams[0]
+    W, H, spp, bounces, frames = 88, 56, 2, 5, 11
+    res = api.build_pathtrace_resources(gpu_ctx, api.BakedPathtraceParams(max_bounces=bounces, samples_per_pixel=spp))
+
+    def cam_for(k):
+        t = np.array(cam.transform, np.float32).copy()
+        t[3, 0] += np.float32(0.01 * k)           # the camera drifts: every frame of a batch has its own
+        return t, api.CameraParams(**{**cam.params.__dict__, "aspect": W / H, "lens": cam.params.lens * (1.0 + 0.01 * (k % 3))})
+
+    def counter(k):
+        return k if k < 6 else k - 6              # a restart at frame 6: the blend chain begins again inside a batch
+
+    def render(batch):
+        gpu_ctx.set_batch_frames(batch)
+        out = api.DoubleBufferedTexture(gpu_ctx, W, H)
+        stray = api.Texture(gpu_ctx, W, H)
+        snaps = []
+        for k in range(frames):
+            t, cp = cam_for(k)
+            desc = api.PathtraceDesc(accum_params=api.AccumulationParams(out.back(), counter(k)), camera_params=cp, camera_transform=t)
+            if k == 4:
+                api.pathtrace_scene_tiles(gpu_ctx, res, scene, out.front(), ptype, desc, 2, 0, 1)   # another dispatch shape: its own wavefront
+            else:
+                api.pathtrace_scene(gpu_ctx, res, scene, out.front(), ptype, desc)
+            if k == 8:   # a call outside the chain (reads `stray`, which no call of the batch wrote)
+                api.pathtrace_scene(gpu_ctx, res, scene, stray, ptype,
+                                    api.PathtraceDesc(accum_params=api.AccumulationParams(out.front(), 3), camera_params=cp, camera_transform=t))
+            if k in (2, 9):
+                snaps.append(out.front().download())   # a read in the middle of a batch
+            out.flip()
+        out.flip()
+        snaps += [out.front().download(), out.back().download(), stray.download()]
+        return snaps
+
+    try:
+        one = render(1)
+        eight = render(8)
+        three = render(3)
+    finally:
+        gpu_ctx.set_batch_frames(4)
+    for a, b, c in zip(one, eight, three):
+        assert util.f16_words_differ(a, b) == 0 and util.f16_words_differ(a, c) == 0
+    # and the serial result is the oracle's (frames 6.. restart the accumulation, so the last image depends on frames 6..10 only)
+    from oracle import oracle
+    prev = np.zeros((H, W, 4), np.float16)
+    for k in range(6, frames):
+        t, cp = cam_for(k)
+        prev, _ = oracle.pathtrace(scene, W, H, cp, t, bounces, spp, ptype, accum_counter=counter(k), prev_frame=prev)
+    assert util.f16_words_differ(one[-3], prev) == 0
+    with pytest.raises(api.LupinError):
+        gpu_ctx.set_batch_frames(9)
+
+
 def test_error_behaviour(gpu_ctx):
     scene, cams = util.load_scene("cornellbox_builtin", gpu_ctx)
     res = api.build_pathtrace_resources(gpu_ctx, api.BakedPathtraceParams())
