@@ -80,7 +80,7 @@ struct LupinContext
     bool timing = false;
     int path_records = -1;          // LUPIN_PATH_RECORDS=0/1: path state as planes / 128-byte records (default: records where the queues are sorted)
     bool sort_window = true;        // LUPIN_SORT_WINDOW=0: k_shade sorts its own 256 paths instead of the k_sort_queue pass
-    int light_stage = 0;            // LUPIN_LIGHT_STAGE=1: sample_lights_pdf in its own stage (k_light_pdf) instead of inline in k_shade
+    int light_stage = -1;           // LUPIN_LIGHT_STAGE=0/1: sample_lights_pdf inline in k_shade / in its own stage (k_light_pdf, k_light_pdf_mis); default: stage for MIS only
     bool debug_sync = false;        // LUPIN_DEBUG_SYNC=1: synchronise and report after every stage launch (fault localisation)
     bool counting = false;          // lupin_hip_stats_reset(ctx, 2): the tracing kernels run their work-counting instantiation
     int accum_mode = 0;             // LUPIN_ACCUM_F16_RUNNING_AVERAGE | LUPIN_ACCUM_F32
@@ -541,10 +541,14 @@ static uint32_t persistent_grid(LupinContext *ctx, const LupinScene *scene, uint
 
 // LUPIN_LIGHT_STAGE=1: sample_lights_pdf of the Standard / MIS integrators runs in its own stage (k_light_pdf / k_light_pdf_mis) instead of inline
 // in k_shade.  Same results; off by default (faster kernel for kernel, slower with frames in flight).
-static bool use_light_stage(const LupinContext *ctx, const LupinScene *scene)
+static bool use_light_stage(const LupinContext *ctx, const LupinScene *scene, uint32_t type)
 {
     if (scene->simple_matte && ctx->specialize_simple) return false;
-    return ctx->light_stage > 0;
+    if (ctx->light_stage >= 0) return ctx->light_stage > 0;
+    // default: MIS runs its two sample_lights_pdf evaluations per vertex in k_light_pdf_mis (k_shade<MIS, DEFER> is then
+    // straight-line BSDF code at 138 VGPRs instead of 256 + scratch with the marches inline); the Standard integrator keeps
+    // its single evaluation inline (faster with frames in flight)
+    return type == LUPIN_PATHTRACE_MIS;
 }
 
 // launch shape of one call's stage kernels
@@ -634,7 +638,7 @@ static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *sc
         fprintf(stderr, "[lupin] iteration %u type %d: extend done: %s\n", iter, TYPE, hipGetErrorString(de)); fflush(stderr);
     }
     bool light_stage = false;
-    if constexpr (TYPE == LUPIN_PATHTRACE_STANDARD || TYPE == LUPIN_PATHTRACE_MIS) light_stage = use_light_stage(ctx, scene);
+    if constexpr (TYPE == LUPIN_PATHTRACE_STANDARD || TYPE == LUPIN_PATHTRACE_MIS) light_stage = use_light_stage(ctx, scene, TYPE);
     // several material families: sort the queue in windows first, k_shade then finds its 256 paths (nearly) uniform
     SceneDev shade_dev = scene->dev;
     if (scene->dev.sort_shade && ctx->sort_window && scene->dev.num_instances)

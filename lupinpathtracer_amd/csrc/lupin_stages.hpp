@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(LP_BLOCK) k_begin(const FrameParams *__restric
 #define LP_LIGHT_PDF_MIS_WAVES 3
 #endif
 #ifndef LP_MIS_DEFER_SHADE_WAVES
-#define LP_MIS_DEFER_SHADE_WAVES 2
+#define LP_MIS_DEFER_SHADE_WAVES 3
 #endif
 #ifndef LP_SIMPLE_SHADE_WAVES
 #define LP_SIMPLE_SHADE_WAVES 4
@@ -846,12 +846,23 @@ __device__ __forceinline__ f3 clamp_radiance(f3 r, float max_radiance)
     return r;
 }
 
-// shadow rays a vertex wants traced (MIS: BSDF- and light-sampled directions; Direct: the light ray)
+// Shadow rays a vertex wants traced (MIS: BSDF- and light-sampled directions; Direct: the light ray).  A ray goes to the
+// path's shadow record (pb.sh_d0 / sh_f0, sh_d1 / sh_f1) the moment it is known, so that nothing of it stays in registers
+// across the rest of the vertex (round 2 carried both rays in a 17-float struct to the end of the iteration: with the light-
+// pdf marches in between, k_shade<MIS> sat at 256 VGPRs + 448 bytes of scratch).  Only the two valid bits travel on.
 struct ShadowRays
 {
-    f3 org;
-    f3 d0, f0; float s0; bool v0;
-    f3 d1, f1; float s1; bool v1;
+    PathBuffers *pb;     // nullptr: the caller has no use for shadow rays (debug view, Standard / Naive integrators)
+    uint32_t slot;
+    uint32_t flags;      // bit 0: ray 0 valid, bit 1: ray 1 valid
+    __device__ __forceinline__ void emit(int k, f3 org, f3 dir, f3 factor, float scalar)
+    {
+        flags |= 1u << k;
+        if (!pb) return;
+        pb->sh_org[slot] = make_float4(org.x, org.y, org.z, 0.0f);   // both rays leave the vertex; the valid bits follow at the end of the iteration
+        if (k == 0) { pb->sh_d0[slot] = make_float4(dir.x, dir.y, dir.z, scalar); pb->sh_f0[slot] = make_float4(factor.x, factor.y, factor.z, 0.0f); }
+        else        { pb->sh_d1[slot] = make_float4(dir.x, dir.y, dir.z, scalar); pb->sh_f1[slot] = make_float4(factor.x, factor.y, factor.z, 0.0f); }
+    }
 };
 
 struct PathRegs
@@ -948,7 +959,7 @@ __device__ __forceinline__ bool integrate_vertex(const Geo &geo, const SceneDev 
                 if (none_zero3(bsdfcos) && pdf > 0.0f)
                 {
                     // radiance += weight * bsdfcos * emission(light_ray) / pdf   -- traced by k_shadow (:1125-1138)
-                    sh.org = hit_pos; sh.d1 = li; sh.f1 = mul(p.weight, bsdfcos); sh.s1 = pdf; sh.v1 = true;
+                    sh.emit(1, hit_pos, li, mul(p.weight, bsdfcos), pdf);
                 }
                 p.next_emission = false;
             }
@@ -990,50 +1001,62 @@ __device__ __forceinline__ bool integrate_vertex(const Geo &geo, const SceneDev 
             }
             else   // MIS: BSDF sample then light sample, power heuristic (:802-855)
             {
-                #pragma unroll 1
+                // what the BSDF turn computed for its direction is what the weight update after both turns needs again
+                // (:853: weight *= eval_bsdfcos(incoming) / sample_bsdfcos_pdf(incoming), the same pure functions of the same
+                // arguments): kept in four registers instead of being evaluated twice
+                f3 bsdfcos0 = splat(0.0f);
+                float b_pdf0 = 0.0f;
+                bool have0 = false;
+                // DEFER (the light pdfs are computed by k_light_pdf_mis): two copies of the BSDF code, straight-line -- 138 VGPRs.
+                // With the marches inline the loop stays rolled (one copy of the march code) and the barriers below matter.
+                #pragma unroll(DEFER ? 2 : 1)
                 for (int k = 0; k < 2; k++)
                 {
                     const bool light_turn = (k != 0);
+                    // The two turns share one copy of the BSDF code (the loop is not unrolled).  Left alone, the compiler hoists
+                    // every sub-expression of bsdf_eval / bsdf_pdf that depends only on the normal and the outgoing direction out
+                    // of the loop -- for all eight material families at once -- and keeps them alive across both turns and
+                    // their light-pdf marches: 256 VGPRs + 424 bytes of scratch.  The turn's own copies of the two vectors pass
+                    // through an empty asm, so nothing computed from them is loop-invariant any more.
+                    f3 normal_k = normal, outgoing_k = outgoing;
+                    MatPoint mp_k = mp;
+                    asm volatile("" : "+v"(normal_k.x), "+v"(normal_k.y), "+v"(normal_k.z), "+v"(outgoing_k.x), "+v"(outgoing_k.y), "+v"(outgoing_k.z),
+                                      "+v"(mp_k.color.x), "+v"(mp_k.color.y), "+v"(mp_k.color.z), "+v"(mp_k.roughness), "+v"(mp_k.metallic), "+v"(mp_k.ior));
                     f3 mi;
                     if (light_turn) mi = lights_sample(sc, hit_pos, p.rng);
                     else
                     {
                         float rnl = rnd(p.rng);
                         float ra = rnd(p.rng), rb = rnd(p.rng);
-                        mi = bsdf_sample(mp, normal, outgoing, rnl, ra, rb);
+                        mi = bsdf_sample(mp_k, normal_k, outgoing_k, rnl, ra, rb);
                     }
                     if (is_zero3(mi)) break;
                     if (!light_turn) incoming = mi;
 
-                    f3 bsdfcos = bsdf_eval(mp, normal, outgoing, mi);
                     if (DEFER)
                     {
                         // k_light_pdf_mis turns the BSDF pdf parked in the scalar into the MIS weight (or drops the ray)
-                        if (none_zero3(bsdfcos))
-                        {
-                            const float bp = bsdf_pdf(mp, normal, outgoing, mi);
-                            sh.org = hit_pos;
-                            if (!light_turn) { sh.d0 = mi; sh.f0 = mul(p.weight, bsdfcos); sh.s0 = bp; sh.v0 = true; }
-                            else             { sh.d1 = mi; sh.f1 = mul(p.weight, bsdfcos); sh.s1 = bp; sh.v1 = true; }
-                        }
+                        const f3 bsdfcos = bsdf_eval(mp_k, normal_k, outgoing_k, mi);
+                        const float bp = bsdf_pdf(mp_k, normal_k, outgoing_k, mi);
+                        if (!light_turn) { bsdfcos0 = bsdfcos; b_pdf0 = bp; have0 = true; }
+                        if (none_zero3(bsdfcos)) sh.emit(k, hit_pos, mi, mul(p.weight, bsdfcos), bp);
                         continue;
                     }
-                    float light_pdf = lights_pdf(geo, sc, stack, hit_pos, mi, eps);
-                    float b_pdf = bsdf_pdf(mp, normal, outgoing, mi);
+                    // the march first: nothing of the BSDF terms is alive across it
+                    const float light_pdf = lights_pdf(geo, sc, stack, hit_pos, mi, eps);
+                    const f3 bsdfcos = bsdf_eval(mp_k, normal_k, outgoing_k, mi);
+                    const float b_pdf = bsdf_pdf(mp_k, normal_k, outgoing_k, mi);
+                    if (!light_turn) { bsdfcos0 = bsdfcos; b_pdf0 = b_pdf; have0 = true; }
                     float mis_w;
                     if (light_turn) mis_w = (light_pdf * light_pdf) / (light_pdf * light_pdf + b_pdf * b_pdf) / light_pdf;
                     else            mis_w = (b_pdf * b_pdf) / (b_pdf * b_pdf + light_pdf * light_pdf) / b_pdf;
 
-                    if (none_zero3(bsdfcos) && mis_w != 0.0f)
-                    {
-                        // radiance += weight * bsdfcos * emission(mis_ray) * mis_weight   -- traced by k_shadow (:831-849);
-                        // the BSDF-sampled ray's hit also becomes `next_intersection`
-                        sh.org = hit_pos;
-                        if (!light_turn) { sh.d0 = mi; sh.f0 = mul(p.weight, bsdfcos); sh.s0 = mis_w; sh.v0 = true; }
-                        else             { sh.d1 = mi; sh.f1 = mul(p.weight, bsdfcos); sh.s1 = mis_w; sh.v1 = true; }
-                    }
+                    // radiance += weight * bsdfcos * emission(mis_ray) * mis_weight   -- traced by k_shadow (:831-849);
+                    // the BSDF-sampled ray's hit also becomes `next_intersection`
+                    if (none_zero3(bsdfcos) && mis_w != 0.0f) sh.emit(k, hit_pos, mi, mul(p.weight, bsdfcos), mis_w);
                 }
-                p.weight = mul(p.weight, divs(bsdf_eval(mp, normal, outgoing, incoming), bsdf_pdf(mp, normal, outgoing, incoming)));
+                if (have0) p.weight = mul(p.weight, divs(bsdfcos0, b_pdf0));
+                else p.weight = mul(p.weight, divs(bsdf_eval(mp, normal, outgoing, incoming), bsdf_pdf(mp, normal, outgoing, incoming)));   // the BSDF turn broke off: incoming == 0
                 p.next_emission = false;
             }
         }
@@ -1192,7 +1215,9 @@ __device__ __forceinline__ int shade_path(const Geo &geo, const SceneDev &sc, ui
     else { p.medium.density = splat(0.0f); p.medium.scattering = splat(0.0f); p.medium.anisotropy = 0.0f; }
 
     ShadowRays sh;
-    sh.v0 = sh.v1 = false;
+    sh.pb = (TYPE == LUPIN_PATHTRACE_MIS || TYPE == LUPIN_PATHTRACE_DIRECT) ? &pb : nullptr;
+    sh.slot = slot;
+    sh.flags = 0u;
     bool cont = integrate_vertex<TYPE, Geo, SIMPLE, DEFER>(geo, sc, stack, fp, p, hitrec, hit_tri, sh);
     const bool vol_dirty = p.in_medium && !was_in_medium;
     if (DEFER && cont && p.pending)
@@ -1234,10 +1259,8 @@ __device__ __forceinline__ int shade_path(const Geo &geo, const SceneDev &sc, ui
                             (p.next_emission ? META_NEXT_EMISSION : 0u) | (cont ? 0u : META_TERMINATED) | (sample << META_SAMPLE_SHIFT);
         pb.ori_rng[slot] = make_float4(p.ori.x, p.ori.y, p.ori.z, __uint_as_float(p.rng));
         pb.dir_meta[slot] = make_float4(p.dir.x, p.dir.y, p.dir.z, __uint_as_float(nm));
-        const uint32_t flags = (sh.v0 ? 1u : 0u) | (sh.v1 ? 2u : 0u);
-        pb.sh_org[slot] = make_float4(sh.org.x, sh.org.y, sh.org.z, __uint_as_float(flags));
-        if (sh.v0) { pb.sh_d0[slot] = make_float4(sh.d0.x, sh.d0.y, sh.d0.z, sh.s0); pb.sh_f0[slot] = make_float4(sh.f0.x, sh.f0.y, sh.f0.z, 0.0f); }
-        if (sh.v1) { pb.sh_d1[slot] = make_float4(sh.d1.x, sh.d1.y, sh.d1.z, sh.s1); pb.sh_f1[slot] = make_float4(sh.f1.x, sh.f1.y, sh.f1.z, 0.0f); }
+        // the rays themselves went out when they were found (ShadowRays::emit, origin included); what is left are the valid bits
+        pb.sh_org[slot].w = __uint_as_float(sh.flags);
         return SLOT_ALIVE;
     }
     return path_epilogue<TYPE>(fp, fpp, pb, slot, p, sample, cont, vol_dirty, r4) ? SLOT_ALIVE : SLOT_DONE;
@@ -1848,7 +1871,7 @@ __global__ void __launch_bounds__(LP_BLOCK) k_debug(SceneDev sc, FrameParams fp,
             trace_alpha(geo, sc, lds_stack, p.ori, p.dir, p.rng, eps, hitrec, hit_tri);
             if (__float_as_uint(hitrec.w) != HIT_MISS) num_bounces++;   // DEBUG_NUM_BOUNCES++ (:606-608)
             ShadowRays sh;
-            sh.v0 = sh.v1 = false;
+            sh.pb = nullptr; sh.slot = 0u; sh.flags = 0u;
             if (!integrate_vertex<LUPIN_PATHTRACE_STANDARD>(geo, sc, lds_stack, fp, p, hitrec, hit_tri, sh)) break;
             p.bounce++;
             if (p.bounce > (int)fp.max_bounces) break;

@@ -25,7 +25,7 @@ SO = os.path.join(ROOT, "lupinpathtracer_amd", "liblupin_hip.so")
 
 # kernels allowed to use scratch at all: demangled-name prefix -> cap in bytes (spilled registers, no stack objects passed by reference)
 SCRATCH_CAPS = {
-    "void k_shade<1,": 512,      # MIS: two shadow-ray candidates live across the light-pdf marches (tools/kernel_resources.py)
+    "void k_shade<1,": 64,       # MIS with the marches inline (LUPIN_LIGHT_STAGE=0; the default, k_shade<1, .., DEFER>, has none): was 448 in round 2
     "void k_shade<3,": 64,       # Direct
     "void k_shade<0, true, true": 32, "void k_shade<0, false, true": 32,   # SIMPLE (matte-only) specialisation at 128 VGPRs
     "void k_shadow<": 64,
