@@ -15,14 +15,11 @@
 #include "../../include/lupin_detmath.h"
 
 #define LP_DEV __device__ __forceinline__
-// Bulky helpers (materials, lights, textures).  Fully inlined k_shade is 142 KB of code; turning these into real
-// functions (-DLP_OUTLINE_HELPERS) shrinks it to 18 KB + callees but the AMDGPU call ABI spills through scratch and
-// the bench drops 5.25 -> 1.69 Gsamples/s, so inlining stays the default.
-#ifdef LP_OUTLINE_HELPERS
-#define LP_FN __device__ __attribute__((noinline))
-#else
+// Bulky helpers (materials, lights, textures) are force-inlined: as real functions the AMDGPU call ABI spills through
+// scratch (measured in round 1: 5.25 -> 1.69 Gsamples/s), and an out-of-line callee that reached its by-reference arguments
+// through flat pointers into scratch faulted in round 2 (profiles/r03_direct_fault_forensics.md; tools/isa_guard.py keeps
+// the shipped code object free of device calls).
 #define LP_FN __device__ __forceinline__
-#endif
 #define LP_BLOCK 256
 
 namespace lpd {
@@ -785,7 +782,6 @@ LP_DEV float4 lerp_texels(float4 p, float4 q, float f)
     return make_float4(p.x * g + q.x * f, p.y * g + q.y * f, p.z * g + q.z * f, p.w * g + q.w * f);
 }
 
-template <bool CLAMP_V = false>   // CLAMP_V: experiment only (tools/env_residual.py), the reference's sampler repeats on both axes
 LP_FN float4 sample_texture(const SceneDev &sc, uint32_t tex_idx, float u, float v)
 {
     const TextureDev t = sc.textures[tex_idx];
@@ -801,7 +797,6 @@ LP_FN float4 sample_texture(const SceneDev &sc, uint32_t tex_idx, float u, float
     if ((w & (w - 1)) == 0) xa = x0 & (w - 1); else xa = ((x0 % w) + w) % w;
     if ((h & (h - 1)) == 0) ya = y0 & (h - 1); else ya = ((y0 % h) + h) % h;
     int xb = xa + 1 == w ? 0 : xa + 1, yb = ya + 1 == h ? 0 : ya + 1;
-    if (CLAMP_V) { ya = y0 < 0 ? 0 : (y0 > h - 1 ? h - 1 : y0); yb = y0 + 1 < 0 ? 0 : (y0 + 1 > h - 1 ? h - 1 : y0 + 1); }
     float4 top = lerp_texels(fetch_texel(sc, t, xa, ya), fetch_texel(sc, t, xb, ya), fx);
     float4 bot = lerp_texels(fetch_texel(sc, t, xa, yb), fetch_texel(sc, t, xb, yb), fx);
     return lerp_texels(top, bot, fy);
@@ -1058,11 +1053,7 @@ LP_FN f3 environment_radiance(const SceneDev &sc, f3 dir)
         f3 e = mk3(env.emission[0], env.emission[1], env.emission[2]);
         if (env.emission_tex_idx != LUPIN_SENTINEL_IDX)
         {
-#ifdef LP_EXPERIMENT_ENV_V_CLAMP
-            float4 t = sample_texture<true>(sc, env.emission_tex_idx, u, v);
-#else
             float4 t = sample_texture(sc, env.emission_tex_idx, u, v);
-#endif
             e = mul(e, mk3(t.x, t.y, t.z));
         }
         total = add(total, e);
@@ -1717,11 +1708,7 @@ LP_FN float lights_pdf(const Geo &geo, const SceneDev &sc, uint32_t *stack, f3 p
     // candidates in increasing light order, so the sum below has the reference's order and the skipped terms are +0.0f.
     float mesh_pdf = 0.0f;
     const float dd = dot3(incoming, incoming);
-#ifdef LP_EXPERIMENT_NO_CULL       // timing experiments only (wrong images): neither culling nor marching
-    for (uint32_t base = sc.num_lights; base < sc.num_lights; base += 32u)
-#else
     for (uint32_t base = 0; base < sc.num_lights; base += 32u)
-#endif
     {
         const uint32_t cnt = (sc.num_lights - base) < 32u ? (sc.num_lights - base) : 32u;
         uint32_t mask = 0u;
@@ -1740,9 +1727,6 @@ LP_FN float lights_pdf(const Geo &geo, const SceneDev &sc, uint32_t *stack, f3 p
             // (the debug heat maps count every light's tests, so the counting accessor keeps them all)
             if (Geo::kCounting || reach) mask |= 1u << k;
         }
-#ifdef LP_EXPERIMENT_NO_MARCH      // timing experiments only (wrong images): culling without marching
-        mesh_pdf += (float)mask * 1e-30f; mask = 0u;
-#endif
         while (mask)
         {
         const uint32_t i = base + (uint32_t)__builtin_ctz(mask);

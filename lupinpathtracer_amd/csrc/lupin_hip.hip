@@ -58,7 +58,7 @@ struct Lane
     struct GraphKey
     {
         uint64_t scene_id = 0, pb_generation = 0;
-        uint32_t n = 0, blocks = 0, type = 0, iterations = 0, stack_words = 0, lds = 0, pblocks = 0, refill_min = 0, node_steps = 0;
+        uint32_t n = 0, blocks = 0, type = 0, iterations = 0, stack_words = 0, lds = 0, pblocks = 0;
         uint32_t wide_blocks = 0, wide_stack_words = 0;
         int persistent = 0, persistent_shadow = 0, lds_geometry = 0;
         bool operator==(const GraphKey &o) const { return memcmp(this, &o, sizeof(GraphKey)) == 0; }
@@ -72,14 +72,13 @@ struct LupinContext
     int device = 0;
     hipStream_t stream = nullptr;   // primary stream (= lanes[0].stream): every non-pathtrace operation runs here
     Lane lanes[LP_MAX_LANES];
-    int num_lanes = LP_MAX_LANES;   // LUPIN_LANES=1..8 (LUPIN_OVERLAP=0 == 1 lane); see the lane choice in pathtrace_impl
+    int num_lanes = LP_MAX_LANES;   // LUPIN_LANES=1..8; see the lane choice in flush_pending
     bool lanes_from_env = false;
     uint64_t call_index = 0;
     int last_lane = -1;
     hipEvent_t marker = nullptr;
     bool timing = false;
     int path_records = -1;          // LUPIN_PATH_RECORDS=0/1: path state as planes / 128-byte records (default: records where the queues are sorted)
-    bool sort_window = true;        // LUPIN_SORT_WINDOW=0: k_shade sorts its own 256 paths instead of the k_sort_queue pass
     int light_stage = -1;           // LUPIN_LIGHT_STAGE=0/1: sample_lights_pdf inline in k_shade / in its own stage (k_light_pdf, k_light_pdf_mis); default: stage for MIS only
     bool debug_sync = false;        // LUPIN_DEBUG_SYNC=1: synchronise and report after every stage launch (fault localisation)
     bool counting = false;          // lupin_hip_stats_reset(ctx, 2): the tracing kernels run their work-counting instantiation
@@ -89,14 +88,11 @@ struct LupinContext
     bool lds_geometry = true;       // LUPIN_LDS_GEOMETRY=0 keeps small scenes in global memory (A/B runs)
     int persistent_extend = 2;      // LUPIN_EXTEND: "simple" 0 | "persistent" 1 (always) | default 2: persistent for scenes traversed from global memory
     uint32_t num_cus = 256;
-    int blocks_per_cu_override = 0; // LUPIN_EXTEND_BLOCKS_PER_CU
-    uint32_t refill_min = LP_REFILL_MIN;   // LUPIN_REFILL_MIN
     bool specialize_simple = true;          // LUPIN_SIMPLE_SHADE=0: always the general k_shade
     bool use_graph = false;                 // LUPIN_GRAPH=1: replay the lane-private wavefront as a HIP graph (opt-in)
     bool persistent_shadow = true;          // LUPIN_SHADOW=simple: MIS / Direct shadow rays stay in k_shadow even on large scenes
-    uint32_t node_steps = 4;               // LUPIN_NODE_STEPS: node visits per scheduling round of k_extend_persistent
     bool wide_traversal = false;           // LUPIN_TRAVERSAL=wide / lupin_hip_set_traversal: four-wide hierarchy + certificate + re-trace (same images, not faster: DESIGN 5)
-    uint32_t wide_stack_pairs = 20;        // LUPIN_WIDE_STACK: (reference, distance) stack entries per lane of the wide tracer
+    static constexpr uint32_t wide_stack_pairs = 20;   // (reference, distance) stack entries per lane of the wide tracer: 40 KB per block, four blocks per CU
     bool verify_wide = false;              // LUPIN_VERIFY_WIDE=1: every closest-hit query is also checked wide-vs-binary on the device (stats)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_extend, ev_shade, ev_total;
     std::vector<hipEvent_t> ev_pool;
@@ -484,23 +480,23 @@ static uint32_t blas_depth(const LupinBvhNode *nodes, uint32_t count)
 
 // grid of the persistent tracer: as many blocks as the device keeps resident with this scene's traversal-stack size
 // (whole waves per shard); queried once per scene and integrator, outside any stream capture
-template <int TYPE, bool LDSGEO>
+template <int TYPE>
 static uint32_t persistent_grid_t(LupinContext *ctx, const LupinScene *scene, size_t lds)
 {
     uint32_t &cached = const_cast<LupinScene *>(scene)->persistent_blocks[TYPE];
     if (cached == 0)
     {
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extend_persistent<TYPE, LDSGEO, 0, false>, LP_BLOCK, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extend_persistent<TYPE, false, 0, false>, LP_BLOCK, lds) != hipSuccess || per_cu < 1) per_cu = 1;
         // With frames in flight the persistent tracer of one frame shares the chip with the shading of another: when five
         // or more of its blocks fit per CU, three leave that room and the pair finishes sooner (materials1 / environments1
         // +5 %); deeper scenes fit four at most and are latency-bound, they keep them all (bistro-class -9 % with two).
         if (ctx->num_lanes > 1 && per_cu > 4) per_cu = 3;
-        if (ctx->blocks_per_cu_override > 0) per_cu = ctx->blocks_per_cu_override;
         cached = std::max(64u, ctx->num_cus * (uint32_t)per_cu / 64u * 64u);
     }
     return cached;
 }
+
 // grid of the four-wide instantiation (its own LDS footprint and register count)
 template <int TYPE>
 static uint32_t wide_grid_t(LupinContext *ctx, const LupinScene *scene, size_t lds)
@@ -510,7 +506,6 @@ static uint32_t wide_grid_t(LupinContext *ctx, const LupinScene *scene, size_t l
     {
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extend_persistent<TYPE, false, 0, false, true, false>, LP_BLOCK, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-        if (ctx->blocks_per_cu_override > 0) per_cu = ctx->blocks_per_cu_override;
         cached = std::max(64u, ctx->num_cus * (uint32_t)per_cu / 64u * 64u);
     }
     return cached;
@@ -526,16 +521,19 @@ static uint32_t wide_grid(LupinContext *ctx, const LupinScene *scene, uint32_t t
     }
 }
 
-static bool use_persistent(const LupinContext *ctx, bool lds_geo) { return ctx->persistent_extend == 1 || (ctx->persistent_extend == 2 && !lds_geo); }
+// The phase-scheduled persistent tracer serves scenes traversed from global memory; scenes staged in LDS (a few dozen node
+// visits per ray) are faster with one ray per lane (k_extend; Cornell box 6.4 vs 5.4 Gsamples/s in round 1).
+// LUPIN_EXTEND=simple forces k_extend everywhere.
+static bool use_persistent(const LupinContext *ctx, bool lds_geo) { return ctx->persistent_extend != 0 && !lds_geo; }
 static uint32_t persistent_grid(LupinContext *ctx, const LupinScene *scene, uint32_t type, bool lds_geo, size_t lds)
 {
     if (!use_persistent(ctx, lds_geo)) return 0;
     switch (type)
     {
-    case LUPIN_PATHTRACE_STANDARD: return lds_geo ? persistent_grid_t<LUPIN_PATHTRACE_STANDARD, true>(ctx, scene, lds) : persistent_grid_t<LUPIN_PATHTRACE_STANDARD, false>(ctx, scene, lds);
-    case LUPIN_PATHTRACE_MIS: return lds_geo ? persistent_grid_t<LUPIN_PATHTRACE_MIS, true>(ctx, scene, lds) : persistent_grid_t<LUPIN_PATHTRACE_MIS, false>(ctx, scene, lds);
-    case LUPIN_PATHTRACE_NAIVE: return lds_geo ? persistent_grid_t<LUPIN_PATHTRACE_NAIVE, true>(ctx, scene, lds) : persistent_grid_t<LUPIN_PATHTRACE_NAIVE, false>(ctx, scene, lds);
-    default: return lds_geo ? persistent_grid_t<LUPIN_PATHTRACE_DIRECT, true>(ctx, scene, lds) : persistent_grid_t<LUPIN_PATHTRACE_DIRECT, false>(ctx, scene, lds);
+    case LUPIN_PATHTRACE_STANDARD: return persistent_grid_t<LUPIN_PATHTRACE_STANDARD>(ctx, scene, lds);
+    case LUPIN_PATHTRACE_MIS: return persistent_grid_t<LUPIN_PATHTRACE_MIS>(ctx, scene, lds);
+    case LUPIN_PATHTRACE_NAIVE: return persistent_grid_t<LUPIN_PATHTRACE_NAIVE>(ctx, scene, lds);
+    default: return persistent_grid_t<LUPIN_PATHTRACE_DIRECT>(ctx, scene, lds);
     }
 }
 
@@ -564,13 +562,12 @@ struct Shape
 };
 
 // the tracing stage of MODE 0 (closest hits of the integrator loop) or 1 (recorded shadow rays) on the persistent tracer
-template <int TYPE, bool LDSGEO, int MODE>
+template <int TYPE, int MODE>
 static void launch_persistent_tracer(LupinContext *ctx, Lane *ln, const LupinScene *scene, const Shape &sh, uint32_t iter)
 {
     hipStream_t st = ln->stream;
     const FrameParams *fp = ln->d_fp;
     unsigned long long *work = ln->work_counters, *wide = ln->wide_counters;
-    if constexpr (!LDSGEO)
     {
         if (sh.wblocks)
         {
@@ -578,26 +575,26 @@ static void launch_persistent_tracer(LupinContext *ctx, Lane *ln, const LupinSce
             if (ctx->counting)
             {
                 hipLaunchKernelGGL((k_extend_persistent<TYPE, false, MODE, true, true, false>), dim3(sh.wblocks), dim3(LP_BLOCK), sh.wlds, st,
-                                   scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, sh.wstack_words, ctx->node_steps, work, wide);
+                                   scene->dev, fp, ln->pb, iter, ln->stat_counters, LP_REFILL_MIN, sh.wstack_words, LP_NODE_STEPS, work, wide);
                 hipLaunchKernelGGL((k_extend_persistent<TYPE, false, MODE, true, false, true>), dim3(sh.pblocks), dim3(LP_BLOCK), sh.lds, st,
-                                   scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, sh.stack_words, ctx->node_steps, work, wide);
+                                   scene->dev, fp, ln->pb, iter, ln->stat_counters, LP_REFILL_MIN, sh.stack_words, LP_NODE_STEPS, work, wide);
             }
             else
             {
                 hipLaunchKernelGGL((k_extend_persistent<TYPE, false, MODE, false, true, false>), dim3(sh.wblocks), dim3(LP_BLOCK), sh.wlds, st,
-                                   scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, sh.wstack_words, ctx->node_steps, work, wide);
+                                   scene->dev, fp, ln->pb, iter, ln->stat_counters, LP_REFILL_MIN, sh.wstack_words, LP_NODE_STEPS, work, wide);
                 hipLaunchKernelGGL((k_extend_persistent<TYPE, false, MODE, false, false, true>), dim3(sh.pblocks), dim3(LP_BLOCK), sh.lds, st,
-                                   scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, sh.stack_words, ctx->node_steps, work, wide);
+                                   scene->dev, fp, ln->pb, iter, ln->stat_counters, LP_REFILL_MIN, sh.stack_words, LP_NODE_STEPS, work, wide);
             }
             return;
         }
     }
     if (ctx->counting)
-        hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, MODE, true>), dim3(sh.pblocks), dim3(LP_BLOCK), sh.lds, st,
-                           scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, sh.stack_words, ctx->node_steps, work, wide);
+        hipLaunchKernelGGL((k_extend_persistent<TYPE, false, MODE, true>), dim3(sh.pblocks), dim3(LP_BLOCK), sh.lds, st,
+                           scene->dev, fp, ln->pb, iter, ln->stat_counters, LP_REFILL_MIN, sh.stack_words, LP_NODE_STEPS, work, wide);
     else
-        hipLaunchKernelGGL((k_extend_persistent<TYPE, LDSGEO, MODE, false>), dim3(sh.pblocks), dim3(LP_BLOCK), sh.lds, st,
-                           scene->dev, fp, ln->pb, iter, ln->stat_counters, ctx->refill_min, sh.stack_words, ctx->node_steps, work, wide);
+        hipLaunchKernelGGL((k_extend_persistent<TYPE, false, MODE, false>), dim3(sh.pblocks), dim3(LP_BLOCK), sh.lds, st,
+                           scene->dev, fp, ln->pb, iter, ln->stat_counters, LP_REFILL_MIN, sh.stack_words, LP_NODE_STEPS, work, wide);
 }
 
 template <int TYPE, bool LDSGEO>
@@ -617,8 +614,9 @@ static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *sc
             hipLaunchKernelGGL(k_verify_wide<0>, dim3(blocks), dim3(LP_BLOCK), std::max(lds, (size_t)ctx->wide_stack_pairs * 2u * LP_BLOCK * sizeof(uint32_t)), st,
                                scene->dev, fp, ln->pb, iter, ctx->wide_stack_pairs, ln->wide_counters + 2);
     }
-    if (persistent) launch_persistent_tracer<TYPE, LDSGEO, 0>(ctx, ln, scene, sh, iter);
-    else
+    bool traced = false;
+    if constexpr (!LDSGEO) { if (persistent) { launch_persistent_tracer<TYPE, 0>(ctx, ln, scene, sh, iter); traced = true; } }
+    if (!traced)
     {
         const bool opaque = scene->all_opaque && ctx->specialize_simple;
         if (ctx->counting)
@@ -641,7 +639,7 @@ static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *sc
     if constexpr (TYPE == LUPIN_PATHTRACE_STANDARD || TYPE == LUPIN_PATHTRACE_MIS) light_stage = use_light_stage(ctx, scene, TYPE);
     // several material families: sort the queue in windows first, k_shade then finds its 256 paths (nearly) uniform
     SceneDev shade_dev = scene->dev;
-    if (scene->dev.sort_shade && ctx->sort_window && scene->dev.num_instances)
+    if (scene->dev.sort_shade && scene->dev.num_instances)
     {
         const uint32_t windows = ((blocks / LP_SHARDS) * LP_BLOCK + LP_SORT_WINDOW - 1) / LP_SORT_WINDOW;
         // the Standard integrator's persistent tracer leaves the key with the hit; otherwise the pass derives it
@@ -677,18 +675,21 @@ static void launch_iteration_t(LupinContext *ctx, Lane *ln, const LupinScene *sc
     }
     if constexpr (TYPE == LUPIN_PATHTRACE_MIS || TYPE == LUPIN_PATHTRACE_DIRECT)   // shadow rays + path finish (booked with "shade" in the timing)
     {
-        if (persistent && ctx->persistent_shadow)
+        bool pretraced = false;
+        if constexpr (!LDSGEO)
         {
-            // large scenes: the shadow rays go through the phase-scheduled persistent tracer as well, then a light finish pass
-            if constexpr (!LDSGEO)
+            if (persistent && ctx->persistent_shadow)
             {
+                // large scenes: the shadow rays go through the phase-scheduled persistent tracer as well, then a light finish pass
                 if (ctx->verify_wide && scene->has_wide)
                     hipLaunchKernelGGL(k_verify_wide<1>, dim3(blocks), dim3(LP_BLOCK), std::max(lds, (size_t)ctx->wide_stack_pairs * 2u * LP_BLOCK * sizeof(uint32_t)), st,
                                        scene->dev, fp, ln->pb, iter, ctx->wide_stack_pairs, ln->wide_counters + 2);
+                launch_persistent_tracer<TYPE, 1>(ctx, ln, scene, sh, iter);
+                hipLaunchKernelGGL((k_shadow<TYPE, false, true>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, stack_words);
+                pretraced = true;
             }
-            launch_persistent_tracer<TYPE, LDSGEO, 1>(ctx, ln, scene, sh, iter);
-            hipLaunchKernelGGL((k_shadow<TYPE, LDSGEO, true>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, stack_words);
         }
+        if (pretraced) {}   // (k_shadow<.., PRETRACED> has run)
         else
             hipLaunchKernelGGL((k_shadow<TYPE, LDSGEO, false>), dim3(blocks), dim3(LP_BLOCK), lds, st, scene->dev, fp, ln->pb, iter, stack_words);
     }
@@ -824,10 +825,8 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
     ctx->device = device_ordinal;
     ctx->runtime_version = ri.runtime_hip_version;
     hipError_t e = hipSuccess;
-    const char *ov = getenv("LUPIN_OVERLAP");
     const char *nl = getenv("LUPIN_LANES");
     if (nl) { ctx->num_lanes = std::min(LP_MAX_LANES, std::max(1, atoi(nl))); ctx->lanes_from_env = true; }
-    if (ov && strcmp(ov, "0") == 0) ctx->num_lanes = 1;
     for (int k = 0; k < ctx->num_lanes && e == hipSuccess; k++)
     {
         Lane &ln = ctx->lanes[k];
@@ -856,14 +855,11 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0)
     {
-        const char *bpc = getenv("LUPIN_EXTEND_BLOCKS_PER_CU");
-        if (bpc) ctx->blocks_per_cu_override = std::max(0, atoi(bpc));
         ctx->num_cus = (uint32_t)prop.multiProcessorCount;
     }
     const char *dbs = getenv("LUPIN_DEBUG_SYNC");
     ctx->debug_sync = dbs && strcmp(dbs, "0") != 0;
     if (const char *lsg = getenv("LUPIN_LIGHT_STAGE")) ctx->light_stage = atoi(lsg) != 0 ? 1 : 0;
-    if (const char *sw = getenv("LUPIN_SORT_WINDOW")) ctx->sort_window = atoi(sw) != 0;
     if (const char *pr = getenv("LUPIN_PATH_RECORDS")) ctx->path_records = atoi(pr) != 0 ? 1 : 0;
     const char *ssh = getenv("LUPIN_SIMPLE_SHADE");
     if (ssh && strcmp(ssh, "0") == 0) ctx->specialize_simple = false;
@@ -879,14 +875,9 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
     }
     const char *shd = getenv("LUPIN_SHADOW");
     if (shd && strcmp(shd, "simple") == 0) ctx->persistent_shadow = false;
-    const char *ns = getenv("LUPIN_NODE_STEPS");
-    if (ns) ctx->node_steps = (uint32_t)std::min(16, std::max(1, atoi(ns)));
     if (const char *bf = getenv("LUPIN_BATCH")) ctx->batch_frames = (uint32_t)std::min((int)LP_MAX_BATCH, std::max(1, atoi(bf)));
     if (const char *tv = getenv("LUPIN_TRAVERSAL")) ctx->wide_traversal = strcmp(tv, "wide") == 0;
-    if (const char *ws = getenv("LUPIN_WIDE_STACK")) ctx->wide_stack_pairs = (uint32_t)std::min(64, std::max(4, atoi(ws)));
     if (const char *vw = getenv("LUPIN_VERIFY_WIDE")) ctx->verify_wide = atoi(vw) != 0;
-    const char *rm = getenv("LUPIN_REFILL_MIN");
-    if (rm) ctx->refill_min = (uint32_t)std::min(64, std::max(1, atoi(rm)));
     *out_ctx = ctx;
     return LUPIN_OK;
 }
@@ -1706,7 +1697,7 @@ static int flush_pending(LupinContext *ctx)
     int rc = ensure_path_buffers(ctx, ln, n, iterations);
     if (rc != LUPIN_OK) return rc;
     // scenes whose queues get sorted by material read the path state at scattered slots: records; otherwise planes
-    set_path_layout(ln, ctx->path_records < 0 ? (scene->dev.sort_shade && ctx->sort_window) : ctx->path_records != 0);
+    set_path_layout(ln, ctx->path_records < 0 ? (scene->dev.sort_shade != 0) : ctx->path_records != 0);
 
     // grid: every shard gets the same number of blocks, block b serves shard b % LP_SHARDS
     const uint32_t blocks_needed = (n + LP_BLOCK - 1) / LP_BLOCK;
@@ -1746,7 +1737,7 @@ static int flush_pending(LupinContext *ctx)
         Lane::GraphKey key;
         key.scene_id = scene->id; key.pb_generation = ln->pb_generation; key.n = n; key.blocks = blocks; key.type = pathtrace_type;
         key.iterations = iterations; key.stack_words = stack_words; key.lds = (uint32_t)lds; key.pblocks = pblocks;
-        key.refill_min = ctx->refill_min; key.node_steps = ctx->node_steps; key.persistent = ctx->persistent_extend;
+        key.persistent = ctx->persistent_extend;
         key.persistent_shadow = ctx->persistent_shadow ? 1 : 0; key.lds_geometry = lds_geo ? 1 : 0;
         key.wide_blocks = sh.wblocks; key.wide_stack_words = sh.wstack_words;
         const bool have = ln->graph_exec && key == ln->graph_key;

@@ -386,9 +386,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launc
 // The waves of the grid are dealt to the shards round-robin and the waves of a shard hand its queue out among themselves
 // (one atomic per refill).  Every ray is still traced by exactly the same sequence of operations as in k_extend, only by
 // a different lane.
-#ifndef LP_REFILL_MIN
-#define LP_REFILL_MIN 16
-#endif
+constexpr uint32_t LP_REFILL_MIN = 16;   // a wave refills when at least this many of its lanes are empty
+constexpr uint32_t LP_NODE_STEPS = 4;    // node visits per scheduling round at most
 
 // k_sort_queue's key of a path about to be shaded: what k_shade will execute for it.  Material type of the hit (0..7) | miss (8)
 // | inside a medium (9); +16: the material's smooth hint (delta branch); +32 (Standard integrator only): the outcome of the
@@ -1383,7 +1382,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(TYPE == 1 ? (DEFER ? LP_MIS_D
                                                     unsigned long long *shard_stats, uint32_t stack_words)
 {
     const FrameParams fp = *fpp;
-    if (SIMPLE) { sc.num_envs = 0; sc.sort_shade = 0; }   // facts of a simple_matte scene, constant from here on
+    if (SIMPLE) sc.num_envs = 0;   // a fact of a simple_matte scene, constant from here on
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     const auto geo = make_geo<LDSGEO>(sc, lds_stack, stack_words);
     const uint32_t shard = blockIdx.x % LP_SHARDS;
@@ -1393,31 +1392,6 @@ __global__ void __attribute__((amdgpu_waves_per_eu(TYPE == 1 ? (DEFER ? LP_MIS_D
     bool mine = i < count;
     uint32_t slot = 0;
     if (mine) slot = pb.queue[iter & 1][(size_t)shard * pb.shard_cap + i];
-    if (sc.sort_shade && (blockIdx.x / LP_SHARDS) * LP_BLOCK < count)   // block-uniform
-    {
-        // Scenes with several material types: counting-sort the block's 256 paths by what they will execute (material
-        // type of the hit | miss | inside a medium) so that a wave runs one or two BSDF families instead of all of them.
-        // Which thread shades which path does not matter: all path state lives in the path's slot.
-        __shared__ uint32_t bins[16];
-        if (threadIdx.x < 16) bins[threadIdx.x] = 0u;
-        __syncthreads();
-        uint32_t key = 15u;
-        if (mine)
-        {
-            const uint32_t inst = __float_as_uint(pb.hit[slot].w);
-            const uint32_t meta = __float_as_uint(pb.dir_meta[slot].w);
-            key = (meta & META_VOLUME) ? 9u : (inst == HIT_MISS ? 8u : ((sc.instances[inst].flags >> 8) & 7u));
-        }
-        const uint32_t rank = atomicAdd(&bins[key], 1u);
-        __syncthreads();
-        uint32_t base = 0;
-        for (uint32_t k = 0; k < key; k++) base += bins[k];
-        lds_stack[base + rank] = mine ? slot : 0xFFFFFFFFu;   // the traversal stacks are not in use yet
-        __syncthreads();
-        slot = lds_stack[threadIdx.x];
-        mine = slot != 0xFFFFFFFFu;
-        __syncthreads();
-    }
     if (mine)
     {
         const float4 orr = pb.ori_rng[slot];

@@ -5,7 +5,8 @@ mean ratio (i) as rendered, (ii) after pushing OUR image through the golden's ow
 truncating encoder and the `image` crate's decode rule mantissa * 2^(e-136) (loader.rs:1775-1879), per pixel, before the
 4x4 box filter the fixtures keep -- and, selected by the environment, under two candidate deviations:
     LUPIN_EXPERIMENT_ENV_F16_WEIGHTS=1   environment alias weights from the f16 texels instead of the f32 file values
-    LUPIN_HIP_LIB=<build with -DLP_EXPERIMENT_ENV_V_CLAMP>   clamp instead of repeat along v in environment lookups
+    (round 2 also ran it on a build that clamped instead of repeating along v in environment lookups: no change in the
+     7th digit; that build variant has been removed)
 
     python tools/env_residual.py environments1 environments2 materials1 arealights1
 """
