@@ -125,3 +125,47 @@ def test_other_integrators_land_on_the_standard_goldens(gpu_ctx, name, cam_i, pt
     assert abs(ratio - 1.0) < mean_tol, ratio
     if rmse_tol is not None:
         assert rel_rmse < rmse_tol, rel_rmse
+
+
+# The same four integrators WITHOUT the per-sample clamp (max_radiance = 1e30) and with f32 accumulation: what is left between
+# them is Monte-Carlo noise and the reference's documented quirks, not clamp bias.  Measured on MI355X, 1024 spp at 480 x 270
+# (tools/integrator_agreement.py, profiles/r03_integrator_agreement.jsonl), mean ratio to the Standard integrator:
+#   arealights1 (no environment)  cam1  MIS 0.9998  Naive 1.0003  Direct 0.9989     cam2  MIS 1.0001  Naive 1.0003  Direct 1.0033
+#   materials1 cam1  Naive 1.0001  Direct 0.9987   materials4 cam1  Naive 1.0001  Direct 1.0020   features1  1.0006 / 1.0004
+#   MIS on the scenes WITH an environment: 1.30 - 1.46 -- the reference's double-counted environment (pathtracer.wgsl:757-761)
+# So the 2 - 5 % offsets of the clamped pins above are the clamp's estimator-dependent bias; the implementations of the four
+# integrators agree to 0.4 % where the reference's quirks do not apply.
+AGREEMENT = [
+    # scene, camera, integrators compared with Standard
+    ("arealights1", 1, (1, 2, 3)), ("arealights1", 2, (1, 2, 3)),
+    ("materials1", 1, (2, 3)), ("materials4", 1, (2, 3)), ("features1", 1, (2, 3)),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,cam_i,types", AGREEMENT)
+def test_integrators_agree_once_the_clamp_is_out_of_the_way(gpu_ctx, name, cam_i, types):
+    scene, cams = util.load_scene(name, gpu_ctx)
+    cam = cams[cam_i]
+    Wd, Hd, spp, frames = 480, 270, 16, 65
+    params = api.CameraParams(**{**cam.params.__dict__, "aspect": Wd / Hd})
+    adv = api.AdvancedParams(max_radiance=1e30)
+    gpu_ctx.set_accumulation_mode(1)
+    try:
+        means = {}
+        for ptype in (0,) + tuple(types):
+            res = api.build_pathtrace_resources(gpu_ctx, api.BakedPathtraceParams(max_bounces=8, samples_per_pixel=spp))
+            out = api.DoubleBufferedTexture(gpu_ctx, Wd, Hd)
+            for k in range(frames):
+                api.pathtrace_scene(gpu_ctx, res, scene, out.front(), ptype,
+                                    api.PathtraceDesc(accum_params=api.AccumulationParams(out.back(), k), camera_params=params,
+                                                      camera_transform=cam.transform, advanced=adv))
+                out.flip()
+            out.flip()
+            means[ptype] = float(out.front().download_f32()[..., :3].astype(np.float64).mean())
+    finally:
+        gpu_ctx.set_accumulation_mode(0)
+    for t in types:
+        ratio = means[t] / means[0]
+        print(f"AGREE {name} cam{cam_i} type{t}: mean ratio to Standard {ratio:.4f}")
+        assert abs(ratio - 1.0) < 0.01, (name, cam_i, t, ratio)
