@@ -147,7 +147,7 @@ def measure_single_gpu(api, ctx, scene, cam, width, height, bounces, spp, steps,
     rec = {"value": st["path_bounces"] / dt / 1e6, "unit": "Msamples/s", "Mpaths_per_s": st["paths"] / dt / 1e6,
            "ms_per_step": dt / steps * 1e3, "steps": steps, "path_bounces": st["path_bounces"]}
 
-    ksteps = min(steps, 2)
+    ksteps = 4                  # one full batch of frames per wavefront (the library's default): the timed launches are production launches
     ctx.stats_reset(1)
     for _ in range(ksteps):
         step()

@@ -160,7 +160,7 @@ LP_DEV f3 adds(f3 a, float s) { return mk3(a.x + s, a.y + s, a.z + s); }
 LP_DEV f3 neg(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 LP_DEV float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 LP_DEV f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-LP_DEV f3 normalize3(f3 a) { float l = sqrtf(dot3(a, a)); return mk3(a.x / l, a.y / l, a.z / l); }
+LP_DEV f3 normalize3(f3 a) { f3 r; lpm_normalize3f(a.x, a.y, a.z, &r.x, &r.y, &r.z); return r; }   // v * (1 / |v|): lupin_detmath.h
 LP_DEV float minf(float a, float b) { return (b < a) ? b : a; }
 LP_DEV float maxf(float a, float b) { return (a < b) ? b : a; }
 LP_DEV float clampf(float x, float lo, float hi) { return minf(maxf(x, lo), hi); }

@@ -965,7 +965,9 @@ int lupin_hip_reserve_path_state(LupinContext *ctx, uint64_t pixels, uint32_t ma
     if (pixels == 0 || pixels * LP_MAX_BATCH > (uint64_t)QUEUE_SLOT_MASK || samples_per_pixel == 0) return fail(LUPIN_ERR_INVALID_ARGUMENT, "bad path-state reservation");
     HIP_TRY(hipSetDevice(ctx->device));
     const uint32_t iterations = samples_per_pixel * (max_bounces + 1);
-    for (int k = 0; k < ctx->num_lanes; k++)
+    // the lanes the dispatches will rotate over (flush_pending's choice for a scene traced from global memory)
+    const int lanes = ctx->lanes_from_env ? ctx->num_lanes : std::min(ctx->batch_frames > 1 ? 4 : LP_MAX_LANES, ctx->num_lanes);
+    for (int k = 0; k < lanes; k++)
     {
         int rc = ensure_path_buffers(ctx, &ctx->lanes[k], pixels * ctx->batch_frames, iterations);
         if (rc != LUPIN_OK) return rc;
@@ -1631,8 +1633,7 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
     // ---- record the call; run the batch when it is full or cannot grow (DESIGN 5 "Frames per wavefront") ----
     fp.frame_slots = n;
     fp.num_frames = 1;
-    const bool batchable = ctx->batch_frames > 1 && !ctx->timing && !ctx->counting && !ctx->verify_wide && !ctx->debug_sync &&
-                           ctx->accum_mode != LUPIN_ACCUM_F32;
+    const bool batchable = ctx->batch_frames > 1 && !ctx->counting && !ctx->verify_wide && !ctx->debug_sync && ctx->accum_mode != LUPIN_ACCUM_F32;
     if (!ctx->pending.empty())
     {
         // a call joins the batch if it differs from the batch's first call only in camera and accum_counter, and blends with

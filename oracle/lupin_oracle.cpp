@@ -16,7 +16,7 @@
 //   * dot/cross/matrix products are summed left to right, no FMA contraction;
 //   * min(a,b) = b<a ? b : a, max(a,b) = a<b ? b : a (GLSL.std.450 FMin/FMax on ordered input), except in
 //     the ray/box slab test, where they are IEEE minNum/maxNum (the hardware min/max of the target);
-//   * normalize(v) = v / sqrt(dot(v,v)); mix(a,b,t) = a*(1-t) + b*t;
+//   * normalize(v) = v * (1 / sqrt(dot(v,v))) (lpm_normalize3f, one division instead of three); mix(a,b,t) = a*(1-t) + b*t;
 //   * pow(x, 2.0) is x*x (what every Vulkan compiler folds it to; pow of a negative base is
 //     otherwise undefined in WGSL) -- pathtracer.wgsl:2067,2190;
 //   * textureSampleLevel = software bilinear, Repeat addressing, level 0, texel centres at +0.5;
@@ -88,7 +88,7 @@ inline vec3f cross(vec3f a, vec3f b)
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
 inline float length(vec3f a) { return sqrtf(dot(a, a)); }
-inline vec3f normalize(vec3f a) { return a / length(a); }
+inline vec3f normalize(vec3f a) { vec3f r; lpm_normalize3f(a.x, a.y, a.z, &r.x, &r.y, &r.z); return r; }   // v * (1 / |v|): lupin_detmath.h
 inline vec3f sqrt3(vec3f a) { return {sqrtf(a.x), sqrtf(a.y), sqrtf(a.z)}; }
 inline vec3f exp3(vec3f a) { return {lpm_expf(a.x), lpm_expf(a.y), lpm_expf(a.z)}; }
 inline vec3f log3(vec3f a) { return {lpm_logf(a.x), lpm_logf(a.y), lpm_logf(a.z)}; }

@@ -2,7 +2,7 @@
 """Folds the PMC passes of one workload (tools/pmc_passes.sh) into profiles/r02_pmc_traffic.json, the file bench.py reads for
 `roofline.traffic` / `roofline.l2_hit`.
 
-    python tools/pmc_traffic_r02.py <workload key> <path_bounces of the profiled run> <calibration jsonl> <pass dir> ...
+    python tools/pmc_traffic.py <workload key> <path_bounces of the profiled run> <calibration jsonl> <pass dir> ...
 
 HBM-side bytes per kernel = FETCH_SIZE x 1024 x c + WRITE_SIZE x 1024, with the read correction c taken from THIS build's
 calibration (tools/calib/fetch_calib.hip under the same counters, MI355X_MICROARCH.md "calibrate on a known byte count in
@@ -44,7 +44,7 @@ def main():
         if c.get("SQ_ACTIVE_INST_VALU"):
             rec["valu_lane_utilisation"][name] = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64)
         rec["counters_per_unit"][name] = {n: v / units for n, v in sorted(c.items())}
-    out = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    out = os.environ.get("LUPIN_PMC_OUT") or os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     allrec = json.load(open(out)) if os.path.exists(out) else {}
     allrec[key] = rec
     json.dump(allrec, open(out, "w"), indent=1, sort_keys=True)

@@ -5,7 +5,7 @@
 #                                    time: the average durations bench.py's hipEvent pass must agree with)
 #   <tag>_pmc{1..5}/                 PMC passes of the same command (tools/pmc_passes.sh)
 #   <tag>_calib.jsonl                FETCH_SIZE calibration on this build's access patterns (tools/calib/fetch_calib)
-#   profiles/r02_pmc_traffic.json    folded by tools/pmc_traffic_r02.py (bench.py reads it)
+#   profiles/r02_pmc_traffic.json    folded by tools/pmc_traffic.py (bench.py reads it)
 set -e
 TAG=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -35,7 +35,7 @@ profile_workload() {  # key, bench args...
   KEY=$1; shift
   tools/pmc_passes.sh ${TAG}_pmc_${KEY}_ python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-secondary "$@"
   UNITS=$(grep -h '^{"metric"' gpurun_out/${TAG}_pmc_${KEY}_1.log | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['path_bounces']*1.5)")
-  python3 tools/pmc_traffic_r02.py $KEY $UNITS gpurun_out/${TAG}_calib.jsonl gpurun_out/${TAG}_pmc_${KEY}_1 gpurun_out/${TAG}_pmc_${KEY}_2 gpurun_out/${TAG}_pmc_${KEY}_3 gpurun_out/${TAG}_pmc_${KEY}_4 gpurun_out/${TAG}_pmc_${KEY}_5 > gpurun_out/${TAG}_pmc_${KEY}_derived.json
+  python3 tools/pmc_traffic.py $KEY $UNITS gpurun_out/${TAG}_calib.jsonl gpurun_out/${TAG}_pmc_${KEY}_1 gpurun_out/${TAG}_pmc_${KEY}_2 gpurun_out/${TAG}_pmc_${KEY}_3 gpurun_out/${TAG}_pmc_${KEY}_4 gpurun_out/${TAG}_pmc_${KEY}_5 > gpurun_out/${TAG}_pmc_${KEY}_derived.json
 }
 profile_workload bistro_class_3840x2160_b16_spp8_standard
 profile_workload cornellbox_1024x1024_b8_spp8_standard --scene cornellbox --width 1024 --height 1024 --bounces 8
