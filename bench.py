@@ -183,6 +183,12 @@ def measure_single_gpu(api, ctx, scene, cam, width, height, bounces, spp, steps,
             "definition": "bytes REQUESTED by the closest-hit kernel in this build's layout after culling (64 B/node visit + 48 B/triangle "
                           "test + 64 B/instance entry + 56 B path state, device-counted) x units per launch / hipEvent launch time",
         }
+        if traffic_per_unit:
+            # the same kernel at DRAM level (PMC FETCH_SIZE + WRITE_SIZE, calibrated): what fraction of the HBM peak actually crosses
+            # the fabric -- the caches serve the rest of the requested bytes
+            dram = traffic_per_unit * units_per_launch / avg_s / 1e9
+            rec["roofline"]["dram"] = {"bytes_per_unit": traffic_per_unit, "achieved_GBps": dram, "frac_of_peak": dram / HBM_PEAK_GBS,
+                                       "frac_of_measured_peak": dram / peak_measured if peak_measured else None}
         l1_miss = pmc.get("counters_per_unit", {}).get("k_extend", {}).get("TCP_TCC_READ_REQ")
         ceiling = request_ceiling()
         if l1_miss and ceiling and not scene_is_lds_resident(scene):
@@ -194,7 +200,10 @@ def measure_single_gpu(api, ctx, scene, cam, width, height, bounces, spp, steps,
                 "whole_frame": {"requests_per_unit_all_kernels": l1_miss + shade_miss, "bound_ms_per_step": frame_bound_ms,
                                 "measured_ms_per_step": rec["ms_per_step"], "frac": frame_bound_ms / rec["ms_per_step"]},
                 "definition": "TCP_TCC_READ_REQ per path-bounce (PMC pass in profiles/) x units per launch / launch time, against the rate of "
-                              "independent random 64- / 128-byte record fetches measured by tools/calib/gather_probe on this chip"}
+                              "independent random 64- / 128-byte record fetches measured by tools/calib/gather_probe on this chip",
+                "note": "NOT the binding limit (round 3): the four-wide traversal needs 39 % fewer of these requests per ray and runs in the same "
+                        "time, launch for launch (profiles/r03_tracer_per_iteration_*.txt); doubling the L1 accesses costs 19 %, a fifth fewer "
+                        "vector instructions nothing -- the tracer sits on a plateau of latency, L1 access rate and issue (DESIGN.md 5)"}
         if scene_is_lds_resident(scene):
             rec["roofline"]["note"] = ("geometry is staged in LDS (scene < 24 KB): requests are served on-chip; `achieved` / `frac` are the "
                                        "requested bytes against the HBM peak for reference only, not a bound")
