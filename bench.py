@@ -147,7 +147,7 @@ def measure_single_gpu(api, ctx, scene, cam, width, height, bounces, spp, steps,
     rec = {"value": st["path_bounces"] / dt / 1e6, "unit": "Msamples/s", "Mpaths_per_s": st["paths"] / dt / 1e6,
            "ms_per_step": dt / steps * 1e3, "steps": steps, "path_bounces": st["path_bounces"]}
 
-    ksteps = 4                  # one full batch of frames per wavefront (the library's default): the timed launches are production launches
+    ksteps = 8                  # one full batch of frames per wavefront (the library's default): the timed launches are production launches
     ctx.stats_reset(1)
     for _ in range(ksteps):
         step()
@@ -438,7 +438,8 @@ def main():
             "config": {"workload": f"{args.scene} {W}x{H}, {args.bounces} bounces, {args.spp} spp per step, {args.integrator} integrator, software BVH "
                                    f"(BASELINE configs[4] frame; stand-in scene for bistroexterior, SURVEY 8d)",
                        "scene": getattr(scene, "stats", None), "samples_per_pixel_per_step": args.spp,
-                       "spp_total_timed": args.spp * args.steps, "frames_in_flight": lanes_used, "traversal": "wide" if st["wide_traversal"] else "binary",
+                       "spp_total_timed": args.spp * args.steps, "frames_in_flight": lanes_used, "frames_per_wavefront": int(st["frames_per_wavefront"]),
+                       "first_pass_stack_entries": int(st["short_stack_entries"]), "traversal": "wide" if st["wide_traversal"] else "binary",
                        "scene_load_and_build_s": load_s,
                        "sharding": "single dispatch" if comm is None else
                                    f"same frame tile-sharded over {world} ranks, tile {args.tile_size * 4}px round-robin, RCCL gather at readback (C ABI, --gather {args.gather})",

@@ -342,7 +342,7 @@ int lupin_hip_set_f16_store_rounding(LupinContext *ctx, int mode);
  * when it is full or as soon as anything needs its result: lupin_hip_sync, texture download / upload / copy, tonemap, pack /
  * gather, falsecolor / debug calls, statistics, a call that cannot join (other scene / integrator / size / parameters /
  * texture chain), a mode setter, teardown of any object.  An error of a recorded call is reported by the call that runs the
- * batch.  frames in [1, 8], default 4 (LUPIN_BATCH); 1 = every call is its own wavefront.  f32 accumulation and work
+ * batch.  frames in [1, 8], default 8 (LUPIN_BATCH); 1 = every call is its own wavefront.  f32 accumulation and work
  * counting run unbatched (kernel timing keeps the batches: its launches are the production launches, one lane). */
 int lupin_hip_set_batch_frames(LupinContext *ctx, uint32_t frames);
 
@@ -478,8 +478,9 @@ typedef struct LupinStats {
     /* shader-clock cycles (s_memtime, summed over the waves) spent in refill | node | triangle | instance | end-of-traversal
      * rounds and in the whole scheduling loop (the work-counting build waits for each round's loads before reading the clock) */
     uint64_t tracer_cycles[6];
-    /* The wide tracer (always counted): closest-hit queries it took, and how many of them it could not certify and handed
-     * to the binary tracer (the reference's visiting order) -- the fallback rate is wide_retraced / wide_queries. */
+    /* The first pass of a two-pass tracer (always counted) -- the four-wide tracer, or the binary tracer on its short stack:
+     * queries it took, and how many of them it handed to the full-stack binary tracer (uncertified wide results; stack
+     * overflows) -- the fallback rate is wide_retraced / wide_queries. */
     uint64_t wide_queries;
     uint64_t wide_retraced;
     /* LUPIN_VERIFY_WIDE=1: every query also run binary-vs-wide on the device, one ray per lane: rays checked, rays the wide
@@ -488,6 +489,8 @@ typedef struct LupinStats {
     uint64_t verify_reasons[4];     /* flagged rays by reason: second hit within the margin | ill-conditioned hit | triangle outside a box above it | stack bound */
     uint32_t frames_in_flight;      /* lanes the latest pathtrace call could use */
     uint32_t wide_traversal;        /* 1 = the latest pathtrace call ran the four-wide tracer */
+    uint32_t frames_per_wavefront;  /* recorded calls the latest wavefront carried (lupin_hip_set_batch_frames) */
+    uint32_t short_stack_entries;   /* stack entries per lane of the binary tracer's first pass in the latest wavefront; 0 = one pass on the full stack */
 } LupinStats;
 enum LupinStatsMode {
     LUPIN_STATS_PLAIN = 0,           /* path-bounce / path counters only (always on) */

@@ -139,7 +139,7 @@ class StatsC(C.Structure):
                 ("wide_node_visits", C.c_uint64 * 3), ("tracer_rounds", C.c_uint64 * 10), ("tracer_cycles", C.c_uint64 * 6), ("wide_queries", C.c_uint64), ("wide_retraced", C.c_uint64),
                 ("verify_checked", C.c_uint64), ("verify_flagged", C.c_uint64), ("verify_mismatches", C.c_uint64),
                 ("verify_raw_mismatches", C.c_uint64), ("verify_reasons", C.c_uint64 * 4), ("frames_in_flight", C.c_uint32),
-                ("wide_traversal", C.c_uint32)]
+                ("wide_traversal", C.c_uint32), ("frames_per_wavefront", C.c_uint32), ("short_stack_entries", C.c_uint32)]
 
 
 class RuntimeInfoC(C.Structure):

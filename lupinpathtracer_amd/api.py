@@ -186,7 +186,7 @@ class Context:
         check(lib().lupin_hip_reserve_path_state(self.handle, int(pixels), int(max_bounces), int(samples_per_pixel)))
 
     def set_batch_frames(self, frames):
-        """Frames per wavefront: how many consecutive, chained pathtrace_scene calls run as one wavefront (1..8, default 4)."""
+        """Frames per wavefront: how many consecutive, chained pathtrace_scene calls run as one wavefront (1..8, default 8)."""
         check(lib().lupin_hip_set_batch_frames(self.handle, int(frames)))
 
     def set_traversal(self, mode):

@@ -79,6 +79,8 @@ struct LupinContext
     hipEvent_t marker = nullptr;
     bool timing = false;
     int path_records = -1;          // LUPIN_PATH_RECORDS=0/1: path state as planes / 128-byte records (default: records where the queues are sorted)
+    uint32_t short_stack = 31;      // LUPIN_SHORT_STACK=n: first pass of the binary tracer on n stack entries per lane when the scene's depth bound
+                                    // asks for more (31 KB per block: five blocks per CU instead of four); 0 = always the full stack, one pass
     int light_stage = -1;           // LUPIN_LIGHT_STAGE=0/1: sample_lights_pdf inline in k_shade / in its own stage (k_light_pdf, k_light_pdf_mis); default: stage for MIS only
     bool debug_sync = false;        // LUPIN_DEBUG_SYNC=1: synchronise and report after every stage launch (fault localisation)
     bool counting = false;          // lupin_hip_stats_reset(ctx, 2): the tracing kernels run their work-counting instantiation
@@ -104,10 +106,11 @@ struct LupinContext
     std::vector<PendingFrame> pending;
     const LupinScene *pending_scene = nullptr;
     uint32_t pending_type = 0;
-    uint32_t batch_frames = 4;             // LUPIN_BATCH=1..8: calls per wavefront (1 = every call is its own wavefront)
+    uint32_t batch_frames = 8;             // LUPIN_BATCH=1..8: calls per wavefront (1 = every call is its own wavefront)
     bool in_flush = false;
     int last_lanes = 0;                    // frames in flight the latest pathtrace call could use (reported by lupin_hip_stats_get)
     bool last_wide = false;                // ... and whether it ran the four-wide tracer
+    uint32_t last_batch = 0, last_short = 0;   // frames the latest wavefront carried; its first-pass stack entries (0 = one pass)
 };
 
 struct LupinPathtraceResources
@@ -130,8 +133,9 @@ struct LupinScene
     SceneDev dev{};
     std::vector<void *> allocations;
     uint32_t stack_entries = 1;
-    uint32_t persistent_blocks[4] = {0, 0, 0, 0};   // grid of k_extend_persistent per integrator (lazy)
+    uint32_t persistent_blocks[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};   // grid of k_extend_persistent per integrator (lazy); [1]: sharing the chip with other lanes' stages
     uint32_t wide_blocks[4] = {0, 0, 0, 0};         // grid of its four-wide instantiation
+    uint32_t short_blocks[4] = {0, 0, 0, 0};        // grid of its short-stack instantiation
     bool has_wide = false;                          // the four-wide hierarchies were built (scenes traversed from global memory)
     uint64_t leaky_triangles = 0;                   // triangles outside some box above them (reference builder: bins vs partition)
     uint64_t id = 0;                                // unique per created scene (graph cache key)
@@ -481,9 +485,9 @@ static uint32_t blas_depth(const LupinBvhNode *nodes, uint32_t count)
 // grid of the persistent tracer: as many blocks as the device keeps resident with this scene's traversal-stack size
 // (whole waves per shard); queried once per scene and integrator, outside any stream capture
 template <int TYPE>
-static uint32_t persistent_grid_t(LupinContext *ctx, const LupinScene *scene, size_t lds)
+static uint32_t persistent_grid_t(LupinContext *ctx, const LupinScene *scene, size_t lds, bool shares_chip)
 {
-    uint32_t &cached = const_cast<LupinScene *>(scene)->persistent_blocks[TYPE];
+    uint32_t &cached = const_cast<LupinScene *>(scene)->persistent_blocks[shares_chip ? 1 : 0][TYPE];
     if (cached == 0)
     {
         int per_cu = 0;
@@ -491,7 +495,7 @@ static uint32_t persistent_grid_t(LupinContext *ctx, const LupinScene *scene, si
         // With frames in flight the persistent tracer of one frame shares the chip with the shading of another: when five
         // or more of its blocks fit per CU, three leave that room and the pair finishes sooner (materials1 / environments1
         // +5 %); deeper scenes fit four at most and are latency-bound, they keep them all (bistro-class -9 % with two).
-        if (ctx->num_lanes > 1 && per_cu > 4) per_cu = 3;
+        if (shares_chip && per_cu > 4) per_cu = 3;
         cached = std::max(64u, ctx->num_cus * (uint32_t)per_cu / 64u * 64u);
     }
     return cached;
@@ -510,6 +514,29 @@ static uint32_t wide_grid_t(LupinContext *ctx, const LupinScene *scene, size_t l
     }
     return cached;
 }
+// grid of the short-stack instantiation of the binary tracer
+template <int TYPE>
+static uint32_t short_grid_t(LupinContext *ctx, const LupinScene *scene, size_t lds)
+{
+    uint32_t &cached = const_cast<LupinScene *>(scene)->short_blocks[TYPE];
+    if (cached == 0)
+    {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extend_persistent<TYPE, false, 0, false, false, false, true>, LP_BLOCK, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        cached = std::max(64u, ctx->num_cus * (uint32_t)per_cu / 64u * 64u);
+    }
+    return cached;
+}
+static uint32_t short_grid(LupinContext *ctx, const LupinScene *scene, uint32_t type, size_t lds)
+{
+    switch (type)
+    {
+    case LUPIN_PATHTRACE_STANDARD: return short_grid_t<LUPIN_PATHTRACE_STANDARD>(ctx, scene, lds);
+    case LUPIN_PATHTRACE_MIS: return short_grid_t<LUPIN_PATHTRACE_MIS>(ctx, scene, lds);
+    case LUPIN_PATHTRACE_NAIVE: return short_grid_t<LUPIN_PATHTRACE_NAIVE>(ctx, scene, lds);
+    default: return short_grid_t<LUPIN_PATHTRACE_DIRECT>(ctx, scene, lds);
+    }
+}
 static uint32_t wide_grid(LupinContext *ctx, const LupinScene *scene, uint32_t type, size_t lds)
 {
     switch (type)
@@ -525,15 +552,15 @@ static uint32_t wide_grid(LupinContext *ctx, const LupinScene *scene, uint32_t t
 // visits per ray) are faster with one ray per lane (k_extend; Cornell box 6.4 vs 5.4 Gsamples/s in round 1).
 // LUPIN_EXTEND=simple forces k_extend everywhere.
 static bool use_persistent(const LupinContext *ctx, bool lds_geo) { return ctx->persistent_extend != 0 && !lds_geo; }
-static uint32_t persistent_grid(LupinContext *ctx, const LupinScene *scene, uint32_t type, bool lds_geo, size_t lds)
+static uint32_t persistent_grid(LupinContext *ctx, const LupinScene *scene, uint32_t type, bool lds_geo, size_t lds, bool shares_chip)
 {
     if (!use_persistent(ctx, lds_geo)) return 0;
     switch (type)
     {
-    case LUPIN_PATHTRACE_STANDARD: return persistent_grid_t<LUPIN_PATHTRACE_STANDARD>(ctx, scene, lds);
-    case LUPIN_PATHTRACE_MIS: return persistent_grid_t<LUPIN_PATHTRACE_MIS>(ctx, scene, lds);
-    case LUPIN_PATHTRACE_NAIVE: return persistent_grid_t<LUPIN_PATHTRACE_NAIVE>(ctx, scene, lds);
-    default: return persistent_grid_t<LUPIN_PATHTRACE_DIRECT>(ctx, scene, lds);
+    case LUPIN_PATHTRACE_STANDARD: return persistent_grid_t<LUPIN_PATHTRACE_STANDARD>(ctx, scene, lds, shares_chip);
+    case LUPIN_PATHTRACE_MIS: return persistent_grid_t<LUPIN_PATHTRACE_MIS>(ctx, scene, lds, shares_chip);
+    case LUPIN_PATHTRACE_NAIVE: return persistent_grid_t<LUPIN_PATHTRACE_NAIVE>(ctx, scene, lds, shares_chip);
+    default: return persistent_grid_t<LUPIN_PATHTRACE_DIRECT>(ctx, scene, lds, shares_chip);
     }
 }
 
@@ -559,6 +586,9 @@ struct Shape
     uint32_t wblocks = 0;        // four-wide tracer; 0 = off
     size_t wlds = 0;
     uint32_t wstack_words = 0;
+    uint32_t sblocks = 0;        // short-stack first pass of the binary tracer; 0 = off
+    size_t slds = 0;
+    uint32_t sstack_words = 0;
 };
 
 // the tracing stage of MODE 0 (closest hits of the integrator loop) or 1 (recorded shadow rays) on the persistent tracer
@@ -588,6 +618,15 @@ static void launch_persistent_tracer(LupinContext *ctx, Lane *ln, const LupinSce
             }
             return;
         }
+    }
+    if (sh.sblocks && !ctx->counting)
+    {
+        // the binary traversal on a short stack (one more block per CU), then the few queries that needed the full one
+        hipLaunchKernelGGL((k_extend_persistent<TYPE, false, MODE, false, false, false, true>), dim3(sh.sblocks), dim3(LP_BLOCK), sh.slds, st,
+                           scene->dev, fp, ln->pb, iter, ln->stat_counters, LP_REFILL_MIN, sh.sstack_words, LP_NODE_STEPS, work, wide);
+        hipLaunchKernelGGL((k_extend_persistent<TYPE, false, MODE, false, false, true>), dim3(sh.pblocks), dim3(LP_BLOCK), sh.lds, st,
+                           scene->dev, fp, ln->pb, iter, ln->stat_counters, LP_REFILL_MIN, sh.stack_words, LP_NODE_STEPS, work, wide);
+        return;
     }
     if (ctx->counting)
         hipLaunchKernelGGL((k_extend_persistent<TYPE, false, MODE, true>), dim3(sh.pblocks), dim3(LP_BLOCK), sh.lds, st,
@@ -878,6 +917,7 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
     if (const char *bf = getenv("LUPIN_BATCH")) ctx->batch_frames = (uint32_t)std::min((int)LP_MAX_BATCH, std::max(1, atoi(bf)));
     if (const char *tv = getenv("LUPIN_TRAVERSAL")) ctx->wide_traversal = strcmp(tv, "wide") == 0;
     if (const char *vw = getenv("LUPIN_VERIFY_WIDE")) ctx->verify_wide = atoi(vw) != 0;
+    if (const char *ss = getenv("LUPIN_SHORT_STACK")) ctx->short_stack = (uint32_t)std::max(0, atoi(ss));
     *out_ctx = ctx;
     return LUPIN_OK;
 }
@@ -966,7 +1006,7 @@ int lupin_hip_reserve_path_state(LupinContext *ctx, uint64_t pixels, uint32_t ma
     HIP_TRY(hipSetDevice(ctx->device));
     const uint32_t iterations = samples_per_pixel * (max_bounces + 1);
     // the lanes the dispatches will rotate over (flush_pending's choice for a scene traced from global memory)
-    const int lanes = ctx->lanes_from_env ? ctx->num_lanes : std::min(ctx->batch_frames > 1 ? 4 : LP_MAX_LANES, ctx->num_lanes);
+    const int lanes = ctx->lanes_from_env ? ctx->num_lanes : std::min(ctx->batch_frames > 1 ? 1 : LP_MAX_LANES, ctx->num_lanes);
     for (int k = 0; k < lanes; k++)
     {
         int rc = ensure_path_buffers(ctx, &ctx->lanes[k], pixels * ctx->batch_frames, iterations);
@@ -1681,14 +1721,16 @@ static int flush_pending(LupinContext *ctx)
     const LupinTexture *prev = ctx->pending.front().prev;
     const uint32_t W = fp.width, H = fp.height;
 
-    // Lane choice: consecutive calls alternate so that their wavefronts overlap; per-kernel timing needs them serial.
-    // Scenes traced by the persistent kernel use every lane: the middle iterations of a frame hold too few rays to fill the
-    // chip and are bounded by the latency of one traversal, so more frames in flight fill it (an eighth of the 4K frame:
-    // 34.1 -> 30.1 ms with 8 lanes on 8 hardware queues).  Launch-bound LDS-resident scenes are best with three.
-    // With several frames per wavefront (the default) four wavefronts in flight are enough (measured: bistro-class 4K 1 227 ->
-    // 1 248 Msamples/s from eight to four at four frames each), and the path state stays at 16 frames' worth.
+    // Lane choice: consecutive wavefronts alternate over `lanes` streams so that they overlap; per-kernel timing needs them serial.
+    // * A wavefront of ONE frame of a scene traced by the persistent kernel does not fill the chip in its middle iterations
+    //   (bounded by the latency of one traversal): every lane is used (an eighth of the 4K frame: 34.1 -> 30.1 ms with 8 lanes).
+    // * A wavefront of SEVERAL frames (the default: up to eight calls) fills it on its own, and then stages of different
+    //   wavefronts only take LDS, registers and cache from each other: one lane, every stage with the chip to itself
+    //   (bistro-class 4K, eight frames: 159 ms per step on one lane, 175 - 183 on two, 177 on three; profiles/r03_batch_matrix_short.txt).
+    // * Launch-bound LDS-resident scenes are best with four lanes (Cornell box 8.0 against 7.2 Gsamples/s on one).
     const bool lds_scene = scene->dev.geo_blob_words && ctx->lds_geometry;
-    const int lanes = ctx->lanes_from_env ? ctx->num_lanes : std::min(lds_scene ? 3 : (ctx->batch_frames > 1 ? 4 : LP_MAX_LANES), ctx->num_lanes);
+    const int lanes = ctx->lanes_from_env ? ctx->num_lanes : std::min(lds_scene ? 4 : (K > 1 ? 1 : LP_MAX_LANES), ctx->num_lanes);
+    const bool chip_to_itself = lanes == 1 || ctx->timing;
     const int w = ctx->timing ? 0 : (int)(ctx->call_index % (uint64_t)lanes);
     ctx->call_index++;
     Lane *ln = &ctx->lanes[w];
@@ -1713,7 +1755,7 @@ static int flush_pending(LupinContext *ctx)
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (ctx->timing) { t0 = get_event(ctx); t1 = get_event(ctx); hipEventRecord(t0, st); }
 
-    const uint32_t pblocks = persistent_grid(ctx, scene, pathtrace_type, lds_geo, lds);
+    const uint32_t pblocks = persistent_grid(ctx, scene, pathtrace_type, lds_geo, lds, !chip_to_itself);
     Shape sh;
     sh.blocks = blocks; sh.pblocks = pblocks; sh.lds = lds; sh.stack_words = stack_words;
     if (pblocks && !lds_geo && scene->has_wide && ctx->wide_traversal)
@@ -1723,8 +1765,20 @@ static int flush_pending(LupinContext *ctx)
         sh.wlds = (size_t)sh.wstack_words * sizeof(uint32_t);
         sh.wblocks = wide_grid(ctx, scene, pathtrace_type, sh.wlds);
     }
+    if (pblocks && !lds_geo && !sh.wblocks && chip_to_itself && ctx->short_stack && scene->stack_entries > ctx->short_stack)
+    {
+        // A fifth block per CU for scenes whose depth bound asks for more than 32 KB of stack per block (bistro-class: 40):
+        // the tracer is bound by latency x waves (four blocks instead of three: -18 %, five instead of four: -10 %), and the
+        // stack a query actually uses is far below the bound (bistro-class 4K: 33 of 3.5 G queries need more than 20 entries).
+        // Only with the chip to itself: sharing it, the larger tracer loses more to the other lanes' stages than it gains.
+        sh.sstack_words = ctx->short_stack * LP_BLOCK;
+        sh.slds = (size_t)sh.sstack_words * sizeof(uint32_t);
+        sh.sblocks = short_grid(ctx, scene, pathtrace_type, sh.slds);
+    }
     ctx->last_lanes = lanes;
     ctx->last_wide = sh.wblocks != 0;
+    ctx->last_batch = K;
+    ctx->last_short = sh.sblocks ? ctx->short_stack : 0u;
     for (uint32_t k = 0; k < K; k++)
     {
         FrameParams fk = ctx->pending[k].fp;
@@ -1740,7 +1794,7 @@ static int flush_pending(LupinContext *ctx)
         key.iterations = iterations; key.stack_words = stack_words; key.lds = (uint32_t)lds; key.pblocks = pblocks;
         key.persistent = ctx->persistent_extend;
         key.persistent_shadow = ctx->persistent_shadow ? 1 : 0; key.lds_geometry = lds_geo ? 1 : 0;
-        key.wide_blocks = sh.wblocks; key.wide_stack_words = sh.wstack_words;
+        key.wide_blocks = sh.wblocks ? sh.wblocks : sh.sblocks; key.wide_stack_words = sh.wblocks ? sh.wstack_words : sh.sstack_words;
         const bool have = ln->graph_exec && key == ln->graph_key;
         if (!have && ln->graph_exec && !(key == ln->seen_key))
         {
@@ -1901,6 +1955,8 @@ int lupin_hip_stats_get(LupinContext *ctx, LupinStats *out)
     }
     out->frames_in_flight = (uint32_t)std::max(0, ctx->last_lanes);
     out->wide_traversal = ctx->last_wide ? 1u : 0u;
+    out->frames_per_wavefront = ctx->last_batch;
+    out->short_stack_entries = ctx->last_short;
     out->extend_launches = ctx->extend_launches;
     auto sum = [](const std::vector<std::pair<hipEvent_t, hipEvent_t>> &v) {
         double ms = 0.0;

@@ -412,13 +412,17 @@ __device__ __forceinline__ uint32_t shade_sort_key(bool in_medium, bool miss, ui
 // WIDE:   the four-wide hierarchies with the exactness certificate (lupin_device.hpp "Wide traversal"): a query whose
 //         result is not certified writes nothing and leaves its job token in pb.retrace.
 // RETRACE: serves those tokens (a second launch of the binary instantiation): the reference's order, by construction.
-// wide_stats (one writer per launch): [0] queries the wide tracer took, [1] queries it handed to the re-trace.
-template <int TYPE, bool LDSGEO, int MODE, bool COUNT, bool WIDE = false, bool RETRACE = false>
+// SHORT:  the binary traversal on a stack of fewer entries than the scene's depth bound asks for, so that a fifth block fits a
+//         CU's LDS: a query whose stack would overflow writes nothing and leaves its token in pb.retrace like an uncertified
+//         wide query; every other query has executed exactly the reference's sequence.
+// wide_stats (one writer per launch): [0] queries the wide / short tracer took, [1] queries it handed to the re-trace.
+template <int TYPE, bool LDSGEO, int MODE, bool COUNT, bool WIDE = false, bool RETRACE = false, bool SHORT = false>
 __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, const FrameParams *__restrict__ fpp, PathBuffers pb, uint32_t iter,
                                                                 unsigned long long *shard_stats, uint32_t refill_min, uint32_t stack_words, uint32_t nsteps,
                                                                 unsigned long long *work, unsigned long long *wide_stats)
 {
     static_assert(!(WIDE && (LDSGEO || RETRACE)), "the wide hierarchies are traversed from global memory; the re-trace is binary");
+    static_assert(!(SHORT && (WIDE || LDSGEO || RETRACE)), "the short stack is a variant of the binary tracer's first pass");
     const FrameParams fp = *fpp;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stack[];
     const auto base_geo = make_geo<LDSGEO>(sc, lds_stack, stack_words);
@@ -429,7 +433,7 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
     const size_t mode_row = ((size_t)iter * 2u + (MODE == 1 ? 1u : 0u)) * LP_SHARDS;
     const uint32_t *counts = RETRACE ? pb.retrace_counts + mode_row : pb.counts + (size_t)iter * LP_SHARDS;
     if (!RETRACE && MODE == 0 && blockIdx.x == 0 && tid < LP_SHARDS) { const uint32_t c = counts[tid]; if (c) shard_stats[tid * 2 + 0] += c; }   // one writer per shard per launch
-    if ((WIDE || RETRACE) && blockIdx.x == 0 && tid < 64u)
+    if ((WIDE || SHORT || RETRACE) && blockIdx.x == 0 && tid < 64u)
     {
         // the first wave books the launch's job count (no LDS: a static allocation here would cost the 40 KB stack its
         // fourth block per CU)
@@ -456,8 +460,9 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
     const float abs_margin = eps;                                           // wide_threshold's absolute part: the scene's own "closer than this is the same place"
     constexpr uint32_t REF_DONE = 0xFFFFFFFFu;
     constexpr uint32_t REF_EXIT = 0xFFFFFFFEu;                              // "leave the instance": handled with the instance entries (I phase), see pop()
+    constexpr uint32_t REF_OVER = 0xFFFFFFFDu;                              // SHORT: "the stack was too short for this query" (an end of traversal without a result)
     constexpr uint32_t REF_SKIP = 0x3FFFFFFFu;                              // WIDE: "pop again" -- an internal-node reference no scene can hold (index 2^30 - 1)
-    const uint32_t stack_entries = stack_words / LP_BLOCK;                  // WIDE: (reference, distance) pairs -> stack_entries / 2 of them
+    const uint32_t stack_entries = stack_words / LP_BLOCK;                  // WIDE: (reference, distance) pairs -> stack_entries / 2 of them; SHORT: references
 
     // per-lane ray + traversal state
     bool active = false;
@@ -520,8 +525,8 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
             }
         }
         const bool isN = active && !(cur & REF_LEAF);
-        const bool isF = active && cur == REF_DONE;
-        const bool isLeaf = active && (cur & REF_LEAF) && cur != REF_DONE;
+        const bool isF = active && (SHORT ? cur >= REF_OVER : cur == REF_DONE);   // (REF_EXIT has been served above)
+        const bool isLeaf = active && (cur & REF_LEAF) && (SHORT ? cur < REF_OVER : cur != REF_DONE);
         const bool isI = isLeaf && blas_base == 0xFFFFFFFFu;
         const bool isT = isLeaf && !isI;
         const unsigned long long idle = __ballot(!active);
@@ -643,8 +648,12 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
                         const uint32_t near_ref = left_first ? nd.left : nd.right;
                         const uint32_t far_ref = left_first ? nd.right : nd.left;
                         const float dn = __builtin_fminf(ld, rd), df = __builtin_fmaxf(ld, rd);
-                        if (df < best.t) { lds_stack[sp * LP_BLOCK + tid] = far_ref; sp++; }
+                        // SHORT: a push the short stack has no room for hands the query to the full-stack tracer (nothing has been
+                        // written for it yet); same straight-line code as the full stack, the verdict is a select at the end
+                        const bool over = SHORT && df < best.t && sp >= stack_entries;
+                        if (df < best.t && !over) { lds_stack[sp * LP_BLOCK + tid] = far_ref; sp++; }
                         if (dn < best.t) cur = near_ref; else pop();
+                        if (SHORT && over) cur = REF_OVER;
                     }
                 }
             }
@@ -693,11 +702,11 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
         {
             // ---- F: end of a traversal = one iteration of ray_skip_alpha_stochastically (bvh_custom.wgsl:154-180) ----
             if (COUNT) { rs[8]++; rs[9] += cF; phase_id = 4; }
-            if constexpr (WIDE)
+            if constexpr (WIDE || SHORT)
             {
                 // queries without a certificate leave their token for the binary tracer and write nothing: the path state the
                 // re-trace starts from is the one this query started from (alpha skips included: the whole chain is redone)
-                const bool give_up = isF && flagged;
+                const bool give_up = isF && (SHORT ? cur == REF_OVER : flagged);
                 const unsigned long long gm = __ballot(give_up);
                 if (gm)
                 {

@@ -25,7 +25,8 @@ def main():
         st = ctx.stats()
         key = f"{c['scene']}:{c['type']}"
         out["differing_words"][key] = util.f16_words_differ(got, ref[key])
-        out["stats"][key] = {k: st[k] for k in ("frames_in_flight", "wide_traversal", "wide_queries", "wide_retraced", "verify_checked", "verify_mismatches")}
+        out["stats"][key] = {k: st[k] for k in ("frames_in_flight", "frames_per_wavefront", "short_stack_entries", "wide_traversal", "wide_queries", "wide_retraced",
+                                                    "verify_checked", "verify_mismatches")}
     print("RESULT " + json.dumps(out))
 
 

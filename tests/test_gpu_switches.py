@@ -34,6 +34,10 @@ SWITCHES = [
     {"LUPIN_TRAVERSAL": "wide", "LUPIN_VERIFY_WIDE": "1"},
     {"LUPIN_TRAVERSAL": "wide", "LUPIN_LDS_GEOMETRY": "0", "LUPIN_GRAPH": "1", "LUPIN_BATCH": "8"},
     {"LUPIN_DEBUG_SYNC": "1"},
+    # the binary tracer's first pass on a stack far too short for the scene: most queries overflow and take the second pass
+    {"LUPIN_SHORT_STACK": "5"}, {"LUPIN_SHORT_STACK": "0"},
+    {"LUPIN_SHORT_STACK": "5", "LUPIN_BATCH": "1", "LUPIN_LANES": "1"},
+    {"LUPIN_SHORT_STACK": "3", "LUPIN_GRAPH": "1"},
 ]
 
 
@@ -67,3 +71,8 @@ def test_switch_value_renders_the_oracles_image(reference, switch):
         assert big["wide_traversal"] == 0
     if "LUPIN_LANES" in switch:
         assert big["frames_in_flight"] == int(switch["LUPIN_LANES"])
+    if int(switch.get("LUPIN_SHORT_STACK", "0")) > 0 and "LUPIN_TRAVERSAL" not in switch:
+        # the cases chain three frames: one wavefront on one lane, where the short first pass applies
+        assert big["short_stack_entries"] == int(switch["LUPIN_SHORT_STACK"]) and 0 < big["wide_retraced"] < big["wide_queries"], big
+    elif switch.get("LUPIN_SHORT_STACK") == "0":
+        assert big["short_stack_entries"] == 0 and big["wide_queries"] == 0

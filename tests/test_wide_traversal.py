@@ -281,7 +281,8 @@ def test_pipeline_counts_and_reports_the_fallback(gpu_ctx, ptype):
     W, H = 160, 96
     gpu_ctx.stats_reset(0)
     default = util.gpu_accumulate(gpu_ctx, scene, cam, W, H, 2, 3, max_bounces=6, ptype=ptype)
-    assert gpu_ctx.stats()["wide_traversal"] == 0 and gpu_ctx.stats()["wide_queries"] == 0
+    st0 = gpu_ctx.stats()   # the default: binary; a first-pass count can only come from its short-stack pass (deep scenes)
+    assert st0["wide_traversal"] == 0 and (st0["wide_queries"] == 0 or (st0["short_stack_entries"] > 0 and st0["wide_retraced"] * 1000 < st0["wide_queries"]))
     gpu_ctx.set_traversal("wide")
     try:
         gpu_ctx.stats_reset(0)
@@ -352,4 +353,6 @@ print("RESULT", hashlib.sha256(img.tobytes()).hexdigest(), st["wide_traversal"],
     a = [l for l in _child(code, {"LUPIN_TRAVERSAL": "wide"}).splitlines() if l.startswith("RESULT")][0].split()
     b = [l for l in _child(code, {}).splitlines() if l.startswith("RESULT")][0].split()
     assert a[1] == b[1]
-    assert a[2] == "1" and int(a[3]) > 0 and b[2] == "0" and int(b[3]) == 0
+    assert a[2] == "1" and int(a[3]) > 0 and b[2] == "0"   # (b[3] may count the default's short-stack first pass, see above)
+    c = [l for l in _child(code, {"LUPIN_SHORT_STACK": "0"}).splitlines() if l.startswith("RESULT")][0].split()
+    assert c[1] == a[1] and c[2] == "0" and int(c[3]) == 0

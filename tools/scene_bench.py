@@ -82,7 +82,8 @@ def main():
                       "spp_per_step": args.spp, "steps": args.steps, "type": args.type, "Msamples_per_s": st["path_bounces"] / dt / 1e6,
                       "Mpaths_per_s": st["paths"] / dt / 1e6, "ms_per_step": dt / args.steps * 1e3,
                       "bounces_per_path": st["path_bounces"] / st["paths"], "scene_stats": scene.stats, "blas_builder": args.blas, "load_and_build_s": load_s,
-                      "kernel_ms_2steps": {"extend": kst["extend_ms"], "shade": kst["shade_ms"], "total": kst["total_ms"]}, "roofline": roofline}))
+                      "kernel_ms_2steps": {"extend": kst["extend_ms"], "shade": kst["shade_ms"], "total": kst["total_ms"]}, "roofline": roofline,
+                      "first_pass_queries": st.get("wide_queries", 0), "retraced": st.get("wide_retraced", 0)}))
 
 
 if __name__ == "__main__":
