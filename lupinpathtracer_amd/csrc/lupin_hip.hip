@@ -79,8 +79,8 @@ struct LupinContext
     hipEvent_t marker = nullptr;
     bool timing = false;
     int path_records = -1;          // LUPIN_PATH_RECORDS=0/1: path state as planes / 128-byte records (default: records where the queues are sorted)
-    uint32_t short_stack = 31;      // LUPIN_SHORT_STACK=n: first pass of the binary tracer on n stack entries per lane when the scene's depth bound
-                                    // asks for more (31 KB per block: five blocks per CU instead of four); 0 = always the full stack, one pass
+    uint32_t short_stack = 26;      // LUPIN_SHORT_STACK=n: first pass of the binary tracer on n stack entries per lane when the scene's depth bound
+                                    // asks for more (26 KB per block: six blocks per CU instead of four); 0 = always the full stack, one pass
     int light_stage = -1;           // LUPIN_LIGHT_STAGE=0/1: sample_lights_pdf inline in k_shade / in its own stage (k_light_pdf, k_light_pdf_mis); default: stage for MIS only
     bool debug_sync = false;        // LUPIN_DEBUG_SYNC=1: synchronise and report after every stage launch (fault localisation)
     bool counting = false;          // lupin_hip_stats_reset(ctx, 2): the tracing kernels run their work-counting instantiation

@@ -387,6 +387,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LP_EXTEND_WAVES, 8))) __launc
 // (one atomic per refill).  Every ray is still traced by exactly the same sequence of operations as in k_extend, only by
 // a different lane.
 constexpr uint32_t LP_REFILL_MIN = 16;   // a wave refills when at least this many of its lanes are empty
+#ifndef LP_SHORT_WAVES
+#define LP_SHORT_WAVES 6   // waves per SIMD the short-stack pass is compiled for (7: 72 registers, 8: 64 -- both measured slower, the spills reach the node loop)
+#endif
 constexpr uint32_t LP_NODE_STEPS = 4;    // node visits per scheduling round at most
 
 // k_sort_queue's key of a path about to be shaded: what k_shade will execute for it.  Material type of the hit (0..7) | miss (8)
@@ -417,7 +420,11 @@ __device__ __forceinline__ uint32_t shade_sort_key(bool in_medium, bool miss, ui
 //         wide query; every other query has executed exactly the reference's sequence.
 // wide_stats (one writer per launch): [0] queries the wide / short tracer took, [1] queries it handed to the re-trace.
 template <int TYPE, bool LDSGEO, int MODE, bool COUNT, bool WIDE = false, bool RETRACE = false, bool SHORT = false>
-__global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, const FrameParams *__restrict__ fpp, PathBuffers pb, uint32_t iter,
+// The short-stack pass is compiled for six waves per SIMD (80 registers; its LDS footprint allows six blocks per CU): the
+// tracer is bound by latency x waves in flight, and the few words the compiler spills (kernel-argument pointers,
+// reloaded in the triangle and end-of-traversal phases) are cheaper than the missing wave.  (Keeping the world ray in LDS
+// instead -- nine registers -- removes no spill and costs an LDS round trip in every scheduling round: measured, rejected.)
+__global__ void __attribute__((amdgpu_waves_per_eu(SHORT ? LP_SHORT_WAVES : (COUNT ? 2 : 4), 8))) __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, const FrameParams *__restrict__ fpp, PathBuffers pb, uint32_t iter,
                                                                 unsigned long long *shard_stats, uint32_t refill_min, uint32_t stack_words, uint32_t nsteps,
                                                                 unsigned long long *work, unsigned long long *wide_stats)
 {
@@ -476,9 +483,11 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
     Closest best;
     best.t = LP_F32_MAX; best.u = 0.0f; best.v = 0.0f; best.tri = 0u; best.inst = HIT_MISS;
 
-    auto start_traversal = [&]() {
-        inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-        co = o; cd = d; cinv = inv_d;
+    // a new query from world origin `no` along `nd` (an alpha skip passes the direction it already has: same bits, same reciprocal)
+    auto start_traversal = [&](f3 no, f3 nd) {
+        const f3 ninv = mk3(1.0f / nd.x, 1.0f / nd.y, 1.0f / nd.z);
+        o = no; d = nd; inv_d = ninv;
+        co = no; cd = nd; cinv = ninv;
         sp = 0; blas_base = 0xFFFFFFFFu;
         cur = sc.num_instances ? (WIDE ? sc.tlas4_root : sc.tlas_root) : REF_DONE;
         best.t = LP_F32_MAX; best.u = 0.0f; best.v = 0.0f; best.tri = 0u; best.inst = HIT_MISS;
@@ -520,7 +529,8 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
         {
             if (active && cur == REF_EXIT)
             {
-                blas_base = 0xFFFFFFFFu; co = o; cd = d; cinv = inv_d;
+                blas_base = 0xFFFFFFFFu;
+                co = o; cd = d; cinv = inv_d;
                 pop();
             }
         }
@@ -563,14 +573,12 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
                 }
                 if (trace)
                 {
-                    o = mk3(orr.x, orr.y, orr.z);
-                    d = mk3(dm.x, dm.y, dm.z);
                     rng = rng_in = __float_as_uint(orr.w);
                     in_medium = (__float_as_uint(dm.w) & META_VOLUME) != 0;
                     total_dst = 0.0f;
                     alpha_k = 0;
                     flagged = false;
-                    start_traversal();
+                    start_traversal(mk3(orr.x, orr.y, orr.z), mk3(dm.x, dm.y, dm.z));
                     active = true;
                 }
             }
@@ -582,10 +590,8 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
                 if (__float_as_uint(so.w) & (1u << ray_k))
                 {
                     const float4 dd = ray_k ? pb.sh_d1[slot] : pb.sh_d0[slot];
-                    o = mk3(so.x, so.y, so.z);
-                    d = mk3(dd.x, dd.y, dd.z);
                     flagged = false;
-                    start_traversal();
+                    start_traversal(mk3(so.x, so.y, so.z), mk3(dd.x, dd.y, dd.z));
                     active = true;
                 }
             }
@@ -685,12 +691,14 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
             {
                 cur_inst = cur & (WIDE ? REF_INDEX_MASK : ~REF_LEAF);
                 const InstanceDev in = geo.inst(cur_inst);
-                co = mk3(o.x * in.r0.x + o.y * in.r0.y + o.z * in.r0.z + 1.0f * in.r0.w,
-                         o.x * in.r1.x + o.y * in.r1.y + o.z * in.r1.z + 1.0f * in.r1.w,
-                         o.x * in.r2.x + o.y * in.r2.y + o.z * in.r2.z + 1.0f * in.r2.w);
-                cd = mk3(d.x * in.r0.x + d.y * in.r0.y + d.z * in.r0.z + 0.0f * in.r0.w,
-                         d.x * in.r1.x + d.y * in.r1.y + d.z * in.r1.z + 0.0f * in.r1.w,
-                         d.x * in.r2.x + d.y * in.r2.y + d.z * in.r2.z + 0.0f * in.r2.w);
+                // a TLAS leaf is reached in world space (blas_base says so): co / cd ARE the world ray, bit for bit
+                const f3 wo = co, wd = cd;
+                co = mk3(wo.x * in.r0.x + wo.y * in.r0.y + wo.z * in.r0.z + 1.0f * in.r0.w,
+                         wo.x * in.r1.x + wo.y * in.r1.y + wo.z * in.r1.z + 1.0f * in.r1.w,
+                         wo.x * in.r2.x + wo.y * in.r2.y + wo.z * in.r2.z + 1.0f * in.r2.w);
+                cd = mk3(wd.x * in.r0.x + wd.y * in.r0.y + wd.z * in.r0.z + 0.0f * in.r0.w,
+                         wd.x * in.r1.x + wd.y * in.r1.y + wd.z * in.r1.z + 0.0f * in.r1.w,
+                         wd.x * in.r2.x + wd.y * in.r2.y + wd.z * in.r2.z + 0.0f * in.r2.w);
                 uint32_t root = in.blas_root;
                 if constexpr (WIDE) root = geo.root4(cur_inst);
                 if (!(root & REF_LEAF)) cinv = mk3(1.0f / cd.x, 1.0f / cd.y, 1.0f / cd.z);
@@ -744,7 +752,6 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
                         float opacity = surface_opacity(sc, sf);
                         if (opacity < 1.0f && rnd(rng) >= opacity)
                         {
-                            o = add(o, scale(d, best.t));
                             alpha_k++;
                             again = alpha_k < 128u;   // MAX_OPACITY_BOUNCES (pathtracer.wgsl:1263)
                         }
@@ -752,7 +759,9 @@ __global__ void __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, con
                 }
                 if (again)
                 {
-                    start_traversal();
+                    // an end of traversal is reached in world space (pop() leaves an instance before it can run out of stack):
+                    // co / cd ARE the world ray here
+                    start_traversal(add(co, scale(cd, best.t)), cd);
                 }
                 else
                 {
