@@ -1707,7 +1707,8 @@ LP_FN float lights_pdf(const Geo &geo, const SceneDev &sc, uint32_t *stack, f3 p
     // radius is padded at upload, the test's own rounding by an explicit error term).  Phase 2: each lane walks its own
     // candidates in increasing light order, so the sum below has the reference's order and the skipped terms are +0.0f.
     float mesh_pdf = 0.0f;
-    const float dd = dot3(incoming, incoming);
+    // (the cull is not part of the arithmetic contract -- it only has to be conservative -- so it uses fused multiply-adds)
+    const float inv_dd = 1.0f / dot3(incoming, incoming);
     for (uint32_t base = 0; base < sc.num_lights; base += 32u)
     {
         const uint32_t cnt = (sc.num_lights - base) < 32u ? (sc.num_lights - base) : 32u;
@@ -1716,12 +1717,15 @@ LP_FN float lights_pdf(const Geo &geo, const SceneDev &sc, uint32_t *stack, f3 p
         {
             const float4 b = sc.light_bounds[base + k];   // centre, padded radius SQUARED
             const f3 v = mk3(b.x - pos.x, b.y - pos.y, b.z - pos.z);
-            const float vv = dot3(v, v), vd = dot3(v, incoming);
-            // distance^2 from the centre to the ray's line, times dd:  vv dd - vd^2  (Lagrange).  Its rounding error is below
-            // 1e-6 vv dd, which the right-hand side adds four times over; hits need t >= eps > 0, so a sphere behind the
-            // origin only counts if the origin is inside it.  The comparisons are written so that NaN / inf keep the light.
+            const float vv = __builtin_fmaf(v.x, v.x, __builtin_fmaf(v.y, v.y, v.z * v.z));
+            const float vd = __builtin_fmaf(v.x, incoming.x, __builtin_fmaf(v.y, incoming.y, v.z * incoming.z));
+            // distance^2 from the centre to the ray's line:  vv - vd^2 / dd.  Its rounding error stays below 1e-6 vv (three fused
+            // steps per dot product, one division per ray), the right-hand side allows eight times that; hits need t >= eps > 0,
+            // so a sphere behind the origin only counts if the origin is inside it.  The comparisons are written so that
+            // NaN / inf keep the light.
+            const float line_d2 = __builtin_fmaf(-(vd * inv_dd), vd, vv);
             const bool behind = vd < 0.0f && eps > 0.0f;
-            const bool out_of_reach = behind ? (vv > b.w) : (vv * dd - vd * vd > (b.w + 4e-6f * vv) * dd);
+            const bool out_of_reach = behind ? (vv > b.w) : (line_d2 > __builtin_fmaf(8e-6f, vv, b.w));
             const bool reach = !out_of_reach;
             // "not provably out of reach": NaN / inf operands keep the light
             // (the debug heat maps count every light's tests, so the counting accessor keeps them all)

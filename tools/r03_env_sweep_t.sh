@@ -1,0 +1,7 @@
+#!/bin/bash
+# bistro-class 4K, integrator $1, under a list of environments
+cd "$GRAFT_REPO_ROOT"
+T=$1; shift
+for E in "$@"; do
+env $E python3 tools/scene_bench.py bistro_class --width 3840 --height 2160 --bounces 16 --steps 8 --warmup 8 --type $T 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('type %d %-40s %8.1f Msamples/s  %7.2f ms/step  extend %.1f shade %.1f ms/2 steps' % (d['type'], sys.argv[1], d['Msamples_per_s'], d['ms_per_step'], d['kernel_ms_2steps']['extend'], d['kernel_ms_2steps']['shade']))" "$E"
+done
