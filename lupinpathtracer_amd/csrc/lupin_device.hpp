@@ -1713,23 +1713,30 @@ LP_FN float lights_pdf(const Geo &geo, const SceneDev &sc, uint32_t *stack, f3 p
     {
         const uint32_t cnt = (sc.num_lights - base) < 32u ? (sc.num_lights - base) : 32u;
         uint32_t mask = 0u;
-        for (uint32_t k = 0; k < cnt; k++)
+        for (uint32_t k4 = 0; k4 < cnt; k4 += 4u)
         {
-            const float4 b = sc.light_bounds[base + k];   // centre, padded radius SQUARED
-            const f3 v = mk3(b.x - pos.x, b.y - pos.y, b.z - pos.z);
-            const float vv = __builtin_fmaf(v.x, v.x, __builtin_fmaf(v.y, v.y, v.z * v.z));
-            const float vd = __builtin_fmaf(v.x, incoming.x, __builtin_fmaf(v.y, incoming.y, v.z * incoming.z));
-            // distance^2 from the centre to the ray's line:  vv - vd^2 / dd.  Its rounding error stays below 1e-6 vv (three fused
-            // steps per dot product, one division per ray), the right-hand side allows eight times that; hits need t >= eps > 0,
-            // so a sphere behind the origin only counts if the origin is inside it.  The comparisons are written so that
-            // NaN / inf keep the light.
-            const float line_d2 = __builtin_fmaf(-(vd * inv_dd), vd, vv);
-            const bool behind = vd < 0.0f && eps > 0.0f;
-            const bool out_of_reach = behind ? (vv > b.w) : (line_d2 > __builtin_fmaf(8e-6f, vv, b.w));
-            const bool reach = !out_of_reach;
-            // "not provably out of reach": NaN / inf operands keep the light
-            // (the debug heat maps count every light's tests, so the counting accessor keeps them all)
-            if (Geo::kCounting || reach) mask |= 1u << k;
+            // four bounds per scalar fetch (64 aligned bytes: the array is padded to whole groups at upload)
+            struct alignas(64) Bounds4 { float4 b[4]; };
+            const Bounds4 q = *reinterpret_cast<const Bounds4 *>(sc.light_bounds + base + k4);
+            #pragma unroll
+            for (uint32_t j = 0; j < 4u; j++)
+            {
+                const uint32_t k = k4 + j;
+                const float4 b = q.b[j];                  // centre, padded radius SQUARED
+                const f3 v = mk3(b.x - pos.x, b.y - pos.y, b.z - pos.z);
+                const float vv = __builtin_fmaf(v.x, v.x, __builtin_fmaf(v.y, v.y, v.z * v.z));
+                const float vd = __builtin_fmaf(v.x, incoming.x, __builtin_fmaf(v.y, incoming.y, v.z * incoming.z));
+                // distance^2 from the centre to the ray's line:  vv - vd^2 / dd.  Its rounding error stays below 1e-6 vv (three
+                // fused steps per dot product, one division per ray), the right-hand side allows eight times that; hits need
+                // t >= eps > 0, so a sphere behind the origin only counts if the origin is inside it.  The comparisons are
+                // written so that NaN / inf keep the light.
+                const float line_d2 = __builtin_fmaf(-(vd * inv_dd), vd, vv);
+                const bool behind = vd < 0.0f && eps > 0.0f;
+                const bool out_of_reach = behind ? (vv > b.w) : (line_d2 > __builtin_fmaf(8e-6f, vv, b.w));
+                // "not provably out of reach": NaN / inf operands keep the light
+                // (the debug heat maps count every light's tests, so the counting accessor keeps them all)
+                if (k < cnt && (Geo::kCounting || !out_of_reach)) mask |= 1u << k;
+            }
         }
         while (mask)
         {

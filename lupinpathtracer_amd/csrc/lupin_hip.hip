@@ -1314,7 +1314,8 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
     // Conservative world-space bounding sphere of every light instance (all mesh vertices through the inverse of the
     // stored world->local rows, in double, radius padded): lights_pdf skips lights whose sphere the ray cannot reach.
     // A skipped light contributes exactly +0.0f in the reference's sum, so results do not change.
-    std::vector<float4> light_bounds(s.num_lights);
+    // (padded to whole groups of four: lights_pdf fetches the bounds four at a time, 64 aligned bytes per scalar load)
+    std::vector<float4> light_bounds(((size_t)s.num_lights + 3) / 4 * 4, make_float4(0.0f, 0.0f, 0.0f, -1.0f));
     for (uint32_t i = 0; i < s.num_lights; i++)
     {
         const LupinInstance &in = s.instances[s.lights[i].instance_idx];

@@ -423,7 +423,8 @@ template <int TYPE, bool LDSGEO, int MODE, bool COUNT, bool WIDE = false, bool R
 // The short-stack pass is compiled for six waves per SIMD (80 registers; its LDS footprint allows six blocks per CU): the
 // tracer is bound by latency x waves in flight, and the few words the compiler spills (kernel-argument pointers,
 // reloaded in the triangle and end-of-traversal phases) are cheaper than the missing wave.  (Keeping the world ray in LDS
-// instead -- nine registers -- removes no spill and costs an LDS round trip in every scheduling round: measured, rejected.)
+// instead -- nine registers -- removes no spill and costs an LDS round trip in every scheduling round: measured, rejected.  The
+// full-stack instantiation at six waves: no change on the shallow scenes that could use it, materials1 / environments1.)
 __global__ void __attribute__((amdgpu_waves_per_eu(SHORT ? LP_SHORT_WAVES : (COUNT ? 2 : 4), 8))) __launch_bounds__(LP_BLOCK) k_extend_persistent(SceneDev sc, const FrameParams *__restrict__ fpp, PathBuffers pb, uint32_t iter,
                                                                 unsigned long long *shard_stats, uint32_t refill_min, uint32_t stack_words, uint32_t nsteps,
                                                                 unsigned long long *work, unsigned long long *wide_stats)

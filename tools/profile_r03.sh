@@ -8,7 +8,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 python3 bench.py > gpurun_out/r03_bench.json 2> gpurun_out/r03_bench.err
 echo "bench done"
-BENCH="python3 bench.py --steps 4 --warmup 4 --no-cpu-baseline --no-kernel-timing --no-secondary"
+BENCH="python3 bench.py --steps 8 --warmup 8 --no-cpu-baseline --no-kernel-timing --no-secondary"
 LUPIN_LANES=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r03_stats_serial -- $BENCH > gpurun_out/r03_stats_serial.log 2>&1
 cp gpurun_out/r03_stats_serial/*/*kernel_stats.csv gpurun_out/r03_kernel_stats_serial.csv
 rm -rf gpurun_out/r03_stats_serial
@@ -17,7 +17,7 @@ export LUPIN_PMC_OUT=$GRAFT_REPO_ROOT/gpurun_out/r03_pmc_traffic.json
 rm -f $LUPIN_PMC_OUT
 profile_workload() {  # key, bench args...
   KEY=$1; shift
-  tools/pmc_passes.sh r03_pmc_${KEY}_ python3 bench.py --steps 4 --warmup 4 --no-cpu-baseline --no-kernel-timing --no-secondary "$@"
+  tools/pmc_passes.sh r03_pmc_${KEY}_ python3 bench.py --steps 8 --warmup 8 --no-cpu-baseline --no-kernel-timing --no-secondary "$@"
   UNITS=$(grep -h '^{"metric"' gpurun_out/r03_pmc_${KEY}_1.log | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['path_bounces']*2.0)")
   python3 tools/pmc_traffic.py $KEY $UNITS profiles/r02_fetch_size_calibration.jsonl gpurun_out/r03_pmc_${KEY}_1 gpurun_out/r03_pmc_${KEY}_2 gpurun_out/r03_pmc_${KEY}_3 gpurun_out/r03_pmc_${KEY}_4 gpurun_out/r03_pmc_${KEY}_5 > gpurun_out/r03_pmc_${KEY}_derived.json
   rm -rf gpurun_out/r03_pmc_${KEY}_[1-5]

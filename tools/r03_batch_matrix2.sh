@@ -2,7 +2,6 @@
 # frames per wavefront x lanes with the short-stack tracer: Msamples/s of the BASELINE configs
 cd "$GRAFT_REPO_ROOT"
 run() { python3 tools/scene_bench.py "$@" 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('%-14s %4dx%-4d  %8.1f Msamples/s  %7.2f ms/step' % (d['scene'], d['width'], d['height'], d['Msamples_per_s'], d['ms_per_step']))"; }
-export LUPIN_SHORT_STACK=31
 for cfg in "$@"; do
   set -- $cfg
   export LUPIN_BATCH=$1 LUPIN_LANES=$2

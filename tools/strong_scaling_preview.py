@@ -21,6 +21,7 @@ scene, cams = util.load_scene("bistro_class", ctx)
 cam = cams[0]
 res = api.build_pathtrace_resources(ctx, api.BakedPathtraceParams(max_bounces=16, samples_per_pixel=8))
 out = api.DoubleBufferedTexture(ctx, args.width, args.height)
+ctx.reserve_path_state(args.width * args.height, 16, 8)
 base = None
 for world in [int(w) for w in args.worlds.split(",")]:
     times, units = [], []
