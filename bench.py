@@ -202,8 +202,9 @@ def measure_single_gpu(api, ctx, scene, cam, width, height, bounces, spp, steps,
                 "definition": "TCP_TCC_READ_REQ per path-bounce (PMC pass in profiles/) x units per launch / launch time, against the rate of "
                               "independent random 64- / 128-byte record fetches measured by tools/calib/gather_probe on this chip",
                 "note": "NOT the binding limit (round 3): the four-wide traversal needs 39 % fewer of these requests per ray and runs in the same "
-                        "time, launch for launch (profiles/r03_tracer_per_iteration_*.txt); doubling the L1 accesses costs 19 %, a fifth fewer "
-                        "vector instructions nothing -- the tracer sits on a plateau of latency, L1 access rate and issue (DESIGN.md 5)"}
+                        "time, launch for launch (profiles/r03_tracer_per_iteration_*.txt), and with six blocks per CU the tracer issues "
+                        "more of them per second than the probe's independent gathers -- it is bound by latency x waves in flight, "
+                        "with the vector ALU at about 60 % (DESIGN.md 5)"}
         if scene_is_lds_resident(scene):
             rec["roofline"]["note"] = ("geometry is staged in LDS (scene < 24 KB): requests are served on-chip; `achieved` / `frac` are the "
                                        "requested bytes against the HBM peak for reference only, not a bound")
