@@ -603,7 +603,11 @@ __global__ void __attribute__((amdgpu_waves_per_eu(SHORT ? LP_SHORT_WAVES : (COU
         if (COUNT) t_round = __builtin_amdgcn_s_memtime();
         int phase_id = 0;
 
-        if (cN >= cT && cN >= cI && cN >= cF)
+        // The vote: lanes at a triangle or at an instance entry count double.  Those rounds are one step long where a node round
+        // is up to four, so serving them early costs little and returns their lanes to the node rounds that dominate
+        // (bistro-class 4K: tracer - 2.9 % against a plain majority; end-of-traversal lanes counted double: + 1.3 %).
+        const uint32_t vN = cN, vT = 2u * cT, vI = 2u * cI, vF = cF;
+        if (vN >= vT && vN >= vI && vN >= vF)
         {
             // ---- N: internal nodes of either level; keeps stepping while at least half of the voters are still at one ----
             if (COUNT) { rs[1]++; phase_id = 1; }
@@ -665,7 +669,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(SHORT ? LP_SHORT_WAVES : (COU
                 }
             }
         }
-        else if (cT >= cI && cT >= cF)
+        else if (vT >= vI && vT >= vF)
         {
             // ---- T: one triangle of a BLAS leaf, first-found wins ties (strict <) ----
             if (COUNT) { rs[4]++; rs[5] += cT; phase_id = 2; }
@@ -684,7 +688,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(SHORT ? LP_SHORT_WAVES : (COU
                 else if (__float_as_uint(tv.v0.w) & LEAF_END_BITS) pop(); else cur++;
             }
         }
-        else if (cI >= cF)
+        else if (vI >= vF)
         {
             // ---- I: enter an instance (bvh_custom.wgsl:28-37) ----
             if (COUNT) { rs[6]++; rs[7] += cI; phase_id = 3; }
