@@ -125,6 +125,7 @@ def measure_single_gpu(api, ctx, scene, cam, width, height, bounces, spp, steps,
     params = camera_for(api, cam, width, height, keep_aspect)
     res = api.build_pathtrace_resources(ctx, api.BakedPathtraceParams(max_bounces=bounces, samples_per_pixel=spp))
     out = api.DoubleBufferedTexture(ctx, width, height)
+    ctx.reserve_path_state(width * height, bounces, spp)
     frame = [0]
 
     def step():
@@ -499,9 +500,11 @@ def single_gpu_extras(args, api, ctx, scene, cam, cam_params, W, H, ptype):
 
     if not args.no_secondary and args.scene == "bistro_class":
         extras["configs"] = []
-        for name, scene_name, w, h, bounces, steps, warm, aspect_keep in (("configs[1] cornellbox 1024x1024 b8", "cornellbox", 1024, 1024, 8, 64, 8, True),
-                                                                         ("configs[2] materials1 1920x1080 b12", "materials1", 1920, 1080, 12, 24, 4, False),
-                                                                         ("configs[3] environments1 1920x1080 b16", "environments1", 1920, 1080, 16, 24, 4, False)):
+        for name, scene_name, w, h, bounces, steps, warm, aspect_keep in (("configs[1] cornellbox 1024x1024 b8", "cornellbox", 1024, 1024, 8, 64, 32, True),
+                                                                         ("configs[2] materials1 1920x1080 b12", "materials1", 1920, 1080, 12, 24, 8, False),
+                                                                         ("configs[3] environments1 1920x1080 b16", "environments1", 1920, 1080, 16, 24, 8, False)):
+            # (warm-up = full wavefronts on every lane the scene will use -- four for the LDS-resident Cornell box -- so that no
+            # lane allocates its path state inside the timed steps)
             sc2, cams2 = load_workload(scene_name, ctx)
             key = f"{scene_name}_{w}x{h}_b{bounces}_spp{args.spp}_standard"
             if args.no_kernel_timing:

@@ -9,5 +9,5 @@ for cfg in "$@"; do
   run bistro_class --width 3840 --height 2160 --bounces 16 --steps 16 --warmup 8
   run materials1 --bounces 12 --steps 32 --warmup 16
   run environments1 --bounces 16 --steps 32 --warmup 16
-  run cornellbox_builtin --width 1024 --height 1024 --bounces 8 --steps 64 --warmup 16
+  run cornellbox_builtin --width 1024 --height 1024 --bounces 8 --steps 64 --warmup 32
 done
