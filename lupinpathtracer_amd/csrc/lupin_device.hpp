@@ -1709,8 +1709,9 @@ LP_FN float lights_pdf(const Geo &geo, const SceneDev &sc, uint32_t *stack, f3 p
     float mesh_pdf = 0.0f;
     // (the cull is not part of the arithmetic contract -- it only has to be conservative -- so it uses fused multiply-adds)
     const float inv_dd = 1.0f / dot3(incoming, incoming);
-    for (uint32_t base = 0; base < sc.num_lights; base += 32u)
-    {
+    // the cull of one group of up to 32 lights starting at `base`: bit k = light base + k may be reached
+    auto cull32 = [&](uint32_t base) -> uint32_t {
+        if (base >= sc.num_lights) return 0u;
         const uint32_t cnt = (sc.num_lights - base) < 32u ? (sc.num_lights - base) : 32u;
         uint32_t mask = 0u;
         for (uint32_t k4 = 0; k4 < cnt; k4 += 4u)
@@ -1738,10 +1739,21 @@ LP_FN float lights_pdf(const Geo &geo, const SceneDev &sc, uint32_t *stack, f3 p
                 if (k < cnt && (Geo::kCounting || !out_of_reach)) mask |= 1u << k;
             }
         }
-        while (mask)
+        return mask;
+    };
+    // Four groups are culled before any light is marched: the march loop below runs as long as the lane with the most
+    // candidates, so one loop over a lane's candidates of 128 lights costs the wave max(sum) iterations where a loop per group
+    // cost sum(max).  Each lane still takes its candidates in increasing light order.
+    for (uint32_t base = 0; base < sc.num_lights; base += 128u)
+    {
+        uint32_t m0 = cull32(base), m1 = cull32(base + 32u), m2 = cull32(base + 64u), m3 = cull32(base + 96u);
+        while (m0 | m1 | m2 | m3)
         {
-        const uint32_t i = base + (uint32_t)__builtin_ctz(mask);
-        mask &= mask - 1u;
+        const uint32_t g = m0 ? 0u : (m1 ? 1u : (m2 ? 2u : 3u));
+        const uint32_t mg = m0 ? m0 : (m1 ? m1 : (m2 ? m2 : m3));
+        const uint32_t i = base + 32u * g + (uint32_t)__builtin_ctz(mg);
+        const uint32_t rest = mg & (mg - 1u);
+        if (g == 0u) m0 = rest; else if (g == 1u) m1 = rest; else if (g == 2u) m2 = rest; else m3 = rest;
         const LupinLight light = sc.lights[i];
         const InstanceDev in = geo.inst(light.instance_idx);
         float light_pdf = 0.0f;
