@@ -216,6 +216,10 @@ static int ensure_path_buffers(LupinContext *ctx0, Lane *ctx, uint64_t slots, ui
             if (*ptrs[k]) { hipFree(*ptrs[k]); *ptrs[k] = nullptr; }
         for (int k = 0; k < NPTRS; k++)
             HIP_TRY(hipMalloc(ptrs[k], (size_t)slots * elem[k]));
+        // touch every page now (a fill runs at several TB/s): otherwise the first wavefront that reaches a slot pays the
+        // mapping of its pages inside its kernels -- 1 % of the first full wavefront of eight 4K frames
+        for (int k = 0; k < NPTRS; k++)
+            HIP_TRY(hipMemsetAsync(*ptrs[k], 0, (size_t)slots * elem[k], ctx->stream));
         ctx->capacity = slots;
     }
     if (iterations + 2 > ctx->counts_capacity)
