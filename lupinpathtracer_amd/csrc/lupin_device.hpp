@@ -1714,13 +1714,14 @@ LP_FN float lights_pdf(const Geo &geo, const SceneDev &sc, uint32_t *stack, f3 p
         if (base >= sc.num_lights) return 0u;
         const uint32_t cnt = (sc.num_lights - base) < 32u ? (sc.num_lights - base) : 32u;
         uint32_t mask = 0u;
-        for (uint32_t k4 = 0; k4 < cnt; k4 += 4u)
+        for (uint32_t k4 = 0; k4 < cnt; k4 += 2u)
         {
-            // four bounds per scalar fetch (64 aligned bytes: the array is padded to whole groups at upload)
-            struct alignas(64) Bounds4 { float4 b[4]; };
-            const Bounds4 q = *reinterpret_cast<const Bounds4 *>(sc.light_bounds + base + k4);
+            // two bounds per scalar fetch (32 aligned bytes; the array is padded to whole groups of four at upload) and two
+            // lights in flight: the packed straight-line form of four costs k_shade its last registers
+            struct alignas(32) Bounds2 { float4 b[2]; };
+            const Bounds2 q = *reinterpret_cast<const Bounds2 *>(sc.light_bounds + base + k4);
             #pragma unroll
-            for (uint32_t j = 0; j < 4u; j++)
+            for (uint32_t j = 0; j < 2u; j++)
             {
                 const uint32_t k = k4 + j;
                 const float4 b = q.b[j];                  // centre, padded radius SQUARED
@@ -1733,7 +1734,10 @@ LP_FN float lights_pdf(const Geo &geo, const SceneDev &sc, uint32_t *stack, f3 p
                 // written so that NaN / inf keep the light.
                 const float line_d2 = __builtin_fmaf(-(vd * inv_dd), vd, vv);
                 const bool behind = vd < 0.0f && eps > 0.0f;
-                const bool out_of_reach = behind ? (vv > b.w) : (line_d2 > __builtin_fmaf(8e-6f, vv, b.w));
+                // (selects, not branches: the loop is wave-uniform and stays straight-line code)
+                const float lhs = behind ? vv : line_d2;
+                const float rhs = behind ? b.w : __builtin_fmaf(8e-6f, vv, b.w);
+                const bool out_of_reach = lhs > rhs;
                 // "not provably out of reach": NaN / inf operands keep the light
                 // (the debug heat maps count every light's tests, so the counting accessor keeps them all)
                 if (k < cnt && (Geo::kCounting || !out_of_reach)) mask |= 1u << k;

@@ -29,6 +29,7 @@ SCRATCH_CAPS = {
     "void k_shade<3,": 64,       # Direct
     "void k_shade<0, true, true": 32, "void k_shade<0, false, true": 32,   # SIMPLE (matte-only) specialisation at 128 VGPRs
     "void k_shadow<": 64,
+    "void k_light_pdf<": 16,     # the opt-in light-pdf stage of the Standard integrator (LUPIN_LIGHT_STAGE=1)
     # the short-stack pass of the tracer is compiled for six waves per SIMD (80 registers): a few kernel-argument pointers are
     # spilled in the prologue and reloaded in the triangle / end-of-traversal phases, none inside the node loop
     "void k_extend_persistent<": 48,
