@@ -117,6 +117,8 @@ struct SceneDev
     const uint32_t *tri_indices; // 3 per global triangle, mesh-local vertex ids
     const InstanceDev *instances;
     const MeshDev *meshes;
+    const MeshDev *inst_meshes;          // per instance: its mesh's record and its material, so that shading fetches them with the
+    const LupinMaterial *inst_materials; // instance index it already has instead of one dependent fetch later
     const LupinMaterial *materials;
     const float4 *normals;
     const float2 *texcoords;
@@ -827,6 +829,7 @@ struct Surface   // a resolved hit: instance, mesh, triangle vertex ids
 {
     InstanceDev in;
     MeshDev mesh;
+    uint32_t inst;
     uint32_t gtri;
     uint32_t i0, i1, i2;
     float u, v;
@@ -836,7 +839,8 @@ LP_DEV Surface resolve_surface(const SceneDev &sc, uint32_t inst, uint32_t gtri,
 {
     Surface s;
     s.in = sc.instances[inst];
-    s.mesh = sc.meshes[s.in.mesh_idx];
+    s.inst = inst;
+    s.mesh = sc.inst_meshes[inst];      // (a copy per instance: fetched beside the instance record, not after it)
     s.gtri = gtri;
     s.i0 = sc.tri_indices[(size_t)gtri * 3 + 0];
     s.i1 = sc.tri_indices[(size_t)gtri * 3 + 1];
@@ -871,7 +875,7 @@ LP_DEV float4 vertex_color(const SceneDev &sc, const Surface &s)
 // color_sample.a * mat.color.a * vert_color.a of get_material_point (pathtracer.wgsl:1314).
 LP_FN float surface_opacity(const SceneDev &sc, const Surface &s)
 {
-    const LupinMaterial *m = &sc.materials[s.in.mat_idx];
+    const LupinMaterial *m = &sc.inst_materials[s.inst];
     float tex_a = 1.0f;
     if (s.mesh.texcoords_base != LUPIN_SENTINEL_IDX && m->color_tex_idx != LUPIN_SENTINEL_IDX)
     {
@@ -889,7 +893,7 @@ LP_FN float surface_opacity(const SceneDev &sc, const Surface &s)
 template <bool SIMPLE = false>
 LP_FN MatPoint material_point(const SceneDev &sc, const Surface &s)
 {
-    const LupinMaterial m = sc.materials[s.in.mat_idx];
+    const LupinMaterial m = sc.inst_materials[s.inst];
     MatPoint r;
     r.type = m.mat_type;
     if (SIMPLE) r.type = LUPIN_MAT_MATTE;   // a compile-time constant: the BSDF switches fold to the matte lobes
@@ -991,7 +995,7 @@ LP_FN f3 shading_normal(const Geo &geo, const SceneDev &sc, const Surface &s)
 
     if (s.mesh.texcoords_base != LUPIN_SENTINEL_IDX)
     {
-        uint32_t ntex = sc.materials[s.in.mat_idx].normal_tex_idx;
+        uint32_t ntex = sc.inst_materials[s.inst].normal_tex_idx;
         if (ntex != LUPIN_SENTINEL_IDX)
         {
             float2 uv0 = sc.texcoords[s.mesh.texcoords_base + s.i0];

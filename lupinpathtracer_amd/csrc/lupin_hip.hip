@@ -1279,6 +1279,14 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
         instances[i] = d;
     }
 
+    // per-instance copies of the mesh record and the material (shading fetches them beside the instance record)
+    std::vector<MeshDev> inst_meshes(s.num_instances);
+    std::vector<LupinMaterial> inst_materials(s.num_instances);
+    for (uint32_t i = 0; i < s.num_instances; i++)
+    {
+        inst_meshes[i] = meshes[s.instances[i].mesh_idx];
+        inst_materials[i] = s.materials[s.instances[i].mat_idx];
+    }
     std::vector<uint32_t> inst_root4(s.num_instances);
     for (uint32_t i = 0; i < s.num_instances; i++) inst_root4[i] = mesh_root4[s.instances[i].mesh_idx];
 
@@ -1393,6 +1401,7 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
     if ((rc = upload(sc, blas, &dv.blas)) || (rc = upload(sc, tris, &dv.tris)) ||
         (rc = upload(sc, tri_indices, &dv.tri_indices)) || (rc = upload(sc, instances, &dv.instances)) ||
         (rc = upload(sc, meshes, &dv.meshes)) || (rc = upload(sc, materials, &dv.materials)) ||
+        (rc = upload(sc, inst_meshes, &dv.inst_meshes)) || (rc = upload(sc, inst_materials, &dv.inst_materials)) ||
         (rc = upload(sc, normals, &dv.normals)) || (rc = upload(sc, texcoords, &dv.texcoords)) || (rc = upload(sc, colors, &dv.colors)) ||
         (rc = upload(sc, textures, &dv.textures)) || (rc = upload(sc, texels, &dv.texels)) ||
         (rc = upload(sc, envs, &dv.environments)) || (rc = upload(sc, lights, &dv.lights)) ||

@@ -1537,7 +1537,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(LP_LIGHT_PDF_MIS_WAVES, 8))) 
 // emission of a surface point: emission_sample * mat.emission of get_material_point (pathtracer.wgsl:1295-1298,1315)
 __device__ __forceinline__ f3 surface_emission(const SceneDev &sc, const Surface &s)
 {
-    const LupinMaterial *m = &sc.materials[s.in.mat_idx];
+    const LupinMaterial *m = &sc.inst_materials[s.inst];
     f3 es = splat(1.0f);
     if (s.mesh.texcoords_base != LUPIN_SENTINEL_IDX && m->emission_tex_idx != LUPIN_SENTINEL_IDX)
     {
