@@ -1043,6 +1043,7 @@ int lupin_hip_scene_create(LupinContext *ctx, const LupinSceneDesc *desc, LupinS
     const LupinSceneDesc &s = *desc;
 
     // ---- validation (validate_scene, data_structures.rs:876-928, plus what the kernels index) ----
+    if (s.num_instances > (1u << 26)) return fail(LUPIN_ERR_INVALID_ARGUMENT, "more than 2^26 instances (the tracer keeps an instance's flags above its 26-bit index)");
     for (uint32_t i = 0; i < s.num_instances; i++)
     {
         if (s.instances[i].mesh_idx >= s.num_meshes) return fail(LUPIN_ERR_INVALID_ARGUMENT, "instance mesh_idx out of range");

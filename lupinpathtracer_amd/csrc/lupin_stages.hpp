@@ -466,6 +466,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(SHORT ? LP_SHORT_WAVES : (COU
 
     const float eps = fp.pc.ray_epsilon;
     const float abs_margin = eps;                                           // wide_threshold's absolute part: the scene's own "closer than this is the same place"
+    // The instance a lane is inside travels with what its end-of-traversal round needs of that instance's flags (alpha bit,
+    // material type, smooth hint: the sort key) in the six bits above the index -- otherwise that round starts with a
+    // dependent fetch of the instance record for one word.  (Scene creation refuses more than 2^26 instances.)
+    constexpr uint32_t INST_TAG_SHIFT = 26u, INST_INDEX_MASK = (1u << INST_TAG_SHIFT) - 1u;
     constexpr uint32_t REF_DONE = 0xFFFFFFFFu;
     constexpr uint32_t REF_EXIT = 0xFFFFFFFEu;                              // "leave the instance": handled with the instance entries (I phase), see pop()
     constexpr uint32_t REF_OVER = 0xFFFFFFFDu;                              // SHORT: "the stack was too short for this query" (an end of traversal without a result)
@@ -696,6 +700,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(SHORT ? LP_SHORT_WAVES : (COU
             {
                 cur_inst = cur & (WIDE ? REF_INDEX_MASK : ~REF_LEAF);
                 const InstanceDev in = geo.inst(cur_inst);
+                const uint32_t inst_index = cur_inst;
+                cur_inst |= ((in.flags & 1u) | (((in.flags >> 8) & 0x1Fu) << 1)) << INST_TAG_SHIFT;
                 // a TLAS leaf is reached in world space (blas_base says so): co / cd ARE the world ray, bit for bit
                 const f3 wo = co, wd = cd;
                 co = mk3(wo.x * in.r0.x + wo.y * in.r0.y + wo.z * in.r0.z + 1.0f * in.r0.w,
@@ -705,7 +711,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(SHORT ? LP_SHORT_WAVES : (COU
                          wd.x * in.r1.x + wd.y * in.r1.y + wd.z * in.r1.z + 0.0f * in.r1.w,
                          wd.x * in.r2.x + wd.y * in.r2.y + wd.z * in.r2.z + 0.0f * in.r2.w);
                 uint32_t root = in.blas_root;
-                if constexpr (WIDE) root = geo.root4(cur_inst);
+                if constexpr (WIDE) root = geo.root4(inst_index);
                 if (!(root & REF_LEAF)) cinv = mk3(1.0f / cd.x, 1.0f / cd.y, 1.0f / cd.z);
                 blas_base = sp;
                 cur = root;
@@ -737,7 +743,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(SHORT ? LP_SHORT_WAVES : (COU
             if (isF && active && MODE == 1)
             {
                 const bool hit = best.t != LP_F32_MAX;
-                const float4 rec = make_float4(hit ? best.t : 0.0f, hit ? best.u : 0.0f, hit ? best.v : 0.0f, __uint_as_float(hit ? best.inst : HIT_MISS));
+                const float4 rec = make_float4(hit ? best.t : 0.0f, hit ? best.u : 0.0f, hit ? best.v : 0.0f, __uint_as_float(hit ? (best.inst & INST_INDEX_MASK) : HIT_MISS));
                 if (TYPE == LUPIN_PATHTRACE_MIS && ray_k == 0) { pb.next_hit[slot] = rec; pb.next_tri[slot] = best.tri; }
                 else { pb.sh_hit1[slot] = rec; pb.sh_f1[slot].w = __uint_as_float(best.tri); }
                 active = false;
@@ -750,7 +756,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(SHORT ? LP_SHORT_WAVES : (COU
                 if (hit)
                 {
                     total_dst += best.t;
-                    inst_flags = sc.instances[best.inst].flags;
+                    const uint32_t tag = best.inst >> INST_TAG_SHIFT;
+                    inst_flags = (tag & 1u) | (((tag >> 1) & 0x1Fu) << 8);
+                    best.inst &= INST_INDEX_MASK;
                     if (inst_flags & 1u)
                     {
                         Surface sf = resolve_surface(sc, best.inst, best.tri, best.u, best.v);
