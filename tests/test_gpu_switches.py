@@ -69,6 +69,13 @@ def test_switch_value_renders_the_oracles_image(reference, switch):
             assert big["verify_checked"] > 0 and big["verify_mismatches"] == 0
     else:
         assert big["wide_traversal"] == 0
+    if not switch:
+        # the default pipeline: the case's three chained frames ran as ONE wavefront on one lane (DESIGN 5 "One wavefront at a time")
+        assert big["frames_per_wavefront"] == 3 and big["frames_in_flight"] == 1, big
+        small = res["stats"]["cornellbox_builtin:0"]
+        assert small["frames_per_wavefront"] == 3 and small["frames_in_flight"] == 4 and small["short_stack_entries"] == 0, small   # LDS-resident: four lanes, one-ray-per-lane tracer
+    if switch.get("LUPIN_BATCH") == "1":
+        assert big["frames_per_wavefront"] == 1 and big["frames_in_flight"] == int(switch.get("LUPIN_LANES", "8")), big
     if "LUPIN_LANES" in switch:
         assert big["frames_in_flight"] == int(switch["LUPIN_LANES"])
     if int(switch.get("LUPIN_SHORT_STACK", "0")) > 0 and "LUPIN_TRAVERSAL" not in switch:
