@@ -148,7 +148,8 @@ def measure_single_gpu(api, ctx, scene, cam, width, height, bounces, spp, steps,
     rec = {"value": st["path_bounces"] / dt / 1e6, "unit": "Msamples/s", "Mpaths_per_s": st["paths"] / dt / 1e6,
            "ms_per_step": dt / steps * 1e3, "steps": steps, "path_bounces": st["path_bounces"]}
 
-    ksteps = 8                  # one full batch of frames per wavefront (the library's default): the timed launches are production launches
+    ksteps = max(1, int(st["frames_per_wavefront"]))   # one full wavefront as the library just ran them: the timed launches are production launches
+    rec["frames_per_wavefront"] = ksteps
     ctx.stats_reset(1)
     for _ in range(ksteps):
         step()
@@ -500,9 +501,9 @@ def single_gpu_extras(args, api, ctx, scene, cam, cam_params, W, H, ptype):
 
     if not args.no_secondary and args.scene == "bistro_class":
         extras["configs"] = []
-        for name, scene_name, w, h, bounces, steps, warm, aspect_keep in (("configs[1] cornellbox 1024x1024 b8", "cornellbox", 1024, 1024, 8, 64, 32, True),
-                                                                         ("configs[2] materials1 1920x1080 b12", "materials1", 1920, 1080, 12, 24, 8, False),
-                                                                         ("configs[3] environments1 1920x1080 b16", "environments1", 1920, 1080, 16, 24, 8, False)):
+        for name, scene_name, w, h, bounces, steps, warm, aspect_keep in (("configs[1] cornellbox 1024x1024 b8", "cornellbox", 1024, 1024, 8, 64, 64, True),
+                                                                         ("configs[2] materials1 1920x1080 b12", "materials1", 1920, 1080, 12, 32, 16, False),
+                                                                         ("configs[3] environments1 1920x1080 b16", "environments1", 1920, 1080, 16, 32, 16, False)):
             # (warm-up = full wavefronts on every lane the scene will use -- four for the LDS-resident Cornell box -- so that no
             # lane allocates its path state inside the timed steps)
             sc2, cams2 = load_workload(scene_name, ctx)

@@ -342,7 +342,8 @@ int lupin_hip_set_f16_store_rounding(LupinContext *ctx, int mode);
  * when it is full or as soon as anything needs its result: lupin_hip_sync, texture download / upload / copy, tonemap, pack /
  * gather, falsecolor / debug calls, statistics, a call that cannot join (other scene / integrator / size / parameters /
  * texture chain), a mode setter, teardown of any object.  An error of a recorded call is reported by the call that runs the
- * batch.  frames in [1, 8], default 8 (LUPIN_BATCH); 1 = every call is its own wavefront.  f32 accumulation and work
+ * batch.  frames in [1, 16] (LUPIN_BATCH), or 0 = chosen by dispatch size, the default: sixteen for dispatches of up to 4 M
+ * pixels, eight above; 1 = every call is its own wavefront.  f32 accumulation and work
  * counting run unbatched (kernel timing keeps the batches: its launches are the production launches, one lane). */
 int lupin_hip_set_batch_frames(LupinContext *ctx, uint32_t frames);
 

@@ -186,7 +186,8 @@ class Context:
         check(lib().lupin_hip_reserve_path_state(self.handle, int(pixels), int(max_bounces), int(samples_per_pixel)))
 
     def set_batch_frames(self, frames):
-        """Frames per wavefront: how many consecutive, chained pathtrace_scene calls run as one wavefront (1..8, default 8)."""
+        """Frames per wavefront: how many consecutive, chained pathtrace_scene calls run as one wavefront (1..16;
+        0 = by dispatch size, the default: 16 up to 4 M pixels, 8 above)."""
         check(lib().lupin_hip_set_batch_frames(self.handle, int(frames)))
 
     def set_traversal(self, mode):

@@ -106,7 +106,8 @@ struct LupinContext
     std::vector<PendingFrame> pending;
     const LupinScene *pending_scene = nullptr;
     uint32_t pending_type = 0;
-    uint32_t batch_frames = 8;             // LUPIN_BATCH=1..8: calls per wavefront (1 = every call is its own wavefront)
+    uint32_t batch_frames = 0;             // LUPIN_BATCH=1..16: calls per wavefront (1 = every call is its own wavefront); 0 = by dispatch size,
+                                           // see frames_per_wavefront()
     bool in_flush = false;
     int last_lanes = 0;                    // frames in flight the latest pathtrace call could use (reported by lupin_hip_stats_get)
     bool last_wide = false;                // ... and whether it ran the four-wide tracer
@@ -918,7 +919,7 @@ int lupin_hip_create_context(int device_ordinal, LupinContext **out_ctx)
     }
     const char *shd = getenv("LUPIN_SHADOW");
     if (shd && strcmp(shd, "simple") == 0) ctx->persistent_shadow = false;
-    if (const char *bf = getenv("LUPIN_BATCH")) ctx->batch_frames = (uint32_t)std::min((int)LP_MAX_BATCH, std::max(1, atoi(bf)));
+    if (const char *bf = getenv("LUPIN_BATCH")) ctx->batch_frames = (uint32_t)std::min((int)LP_MAX_BATCH, std::max(0, atoi(bf)));
     if (const char *tv = getenv("LUPIN_TRAVERSAL")) ctx->wide_traversal = strcmp(tv, "wide") == 0;
     if (const char *vw = getenv("LUPIN_VERIFY_WIDE")) ctx->verify_wide = atoi(vw) != 0;
     if (const char *ss = getenv("LUPIN_SHORT_STACK")) ctx->short_stack = (uint32_t)std::max(0, atoi(ss));
@@ -973,10 +974,20 @@ int lupin_hip_set_f16_store_rounding(LupinContext *ctx, int mode)
     return LUPIN_OK;
 }
 
+// How many recorded calls one wavefront of `pixels`-pixel dispatches may carry.  Left to the library (batch_frames == 0): sixteen up
+// to 4 M pixels -- 1080p launches are the small ones: materials1 / environments1 + 5 % / + 7 % over eight -- and eight above
+// (3840 x 2160: + 0.9 % for twice the path state).  Always within the queue entries' slot bits.
+static uint32_t frames_per_wavefront(const LupinContext *ctx, uint64_t pixels)
+{
+    uint64_t k = ctx->batch_frames ? ctx->batch_frames : (pixels <= (4ull << 20) ? 16u : 8u);
+    if (pixels) k = std::min<uint64_t>(k, (uint64_t)QUEUE_SLOT_MASK / pixels);
+    return (uint32_t)std::max<uint64_t>(k, 1);
+}
+
 int lupin_hip_set_batch_frames(LupinContext *ctx, uint32_t frames)
 {
     CTX_ALIVE_TRY(ctx);
-    if (!ctx || frames < 1 || frames > LP_MAX_BATCH) return fail(LUPIN_ERR_INVALID_ARGUMENT, "frames per wavefront must be in [1, 8]");
+    if (!ctx || frames > LP_MAX_BATCH) return fail(LUPIN_ERR_INVALID_ARGUMENT, "frames per wavefront must be in [1, 16] (0: chosen by dispatch size)");
     int frc = flush_pending(ctx);
     if (frc != LUPIN_OK) return frc;
     ctx->batch_frames = frames;
@@ -1006,14 +1017,15 @@ int lupin_hip_set_accumulation_mode(LupinContext *ctx, int mode)
 int lupin_hip_reserve_path_state(LupinContext *ctx, uint64_t pixels, uint32_t max_bounces, uint32_t samples_per_pixel)
 {
     CTX_ALIVE_TRY(ctx);
-    if (pixels == 0 || pixels * LP_MAX_BATCH > (uint64_t)QUEUE_SLOT_MASK || samples_per_pixel == 0) return fail(LUPIN_ERR_INVALID_ARGUMENT, "bad path-state reservation");
+    if (pixels == 0 || pixels > (uint64_t)QUEUE_SLOT_MASK || samples_per_pixel == 0) return fail(LUPIN_ERR_INVALID_ARGUMENT, "bad path-state reservation");
+    const uint32_t batch = frames_per_wavefront(ctx, pixels);
     HIP_TRY(hipSetDevice(ctx->device));
     const uint32_t iterations = samples_per_pixel * (max_bounces + 1);
     // the lanes the dispatches will rotate over (flush_pending's choice for a scene traced from global memory)
-    const int lanes = ctx->lanes_from_env ? ctx->num_lanes : std::min(ctx->batch_frames > 1 ? 1 : LP_MAX_LANES, ctx->num_lanes);
+    const int lanes = ctx->lanes_from_env ? ctx->num_lanes : std::min(batch > 1 ? 1 : LP_MAX_LANES, ctx->num_lanes);
     for (int k = 0; k < lanes; k++)
     {
-        int rc = ensure_path_buffers(ctx, &ctx->lanes[k], pixels * ctx->batch_frames, iterations);
+        int rc = ensure_path_buffers(ctx, &ctx->lanes[k], pixels * batch, iterations);
         if (rc != LUPIN_OK) return rc;
     }
     return LUPIN_OK;
@@ -1661,7 +1673,7 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
         n64 = (uint64_t)fp.reg_w * fp.reg_h;
     }
     if (n64 == 0) return LUPIN_OK;
-    if (n64 * LP_MAX_BATCH > (uint64_t)QUEUE_SLOT_MASK) return fail(LUPIN_ERR_INVALID_ARGUMENT, "dispatch too large");   // queue entries keep two bits for the light-pdf stage; a wavefront holds up to LP_MAX_BATCH frames
+    if (n64 * 8u > (uint64_t)QUEUE_SLOT_MASK) return fail(LUPIN_ERR_INVALID_ARGUMENT, "dispatch too large");   // queue entries keep two bits for the light-pdf stage; a wavefront of dispatches this size holds up to eight frames (frames_per_wavefront)
     const uint32_t n = (uint32_t)n64;
 
     if (falsecolor_type >= 0 || debug)
@@ -1688,7 +1700,8 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
     // ---- record the call; run the batch when it is full or cannot grow (DESIGN 5 "Frames per wavefront") ----
     fp.frame_slots = n;
     fp.num_frames = 1;
-    const bool batchable = ctx->batch_frames > 1 && !ctx->counting && !ctx->verify_wide && !ctx->debug_sync && ctx->accum_mode != LUPIN_ACCUM_F32;
+    const uint32_t max_frames = frames_per_wavefront(ctx, n64);
+    const bool batchable = max_frames > 1 && !ctx->counting && !ctx->verify_wide && !ctx->debug_sync && ctx->accum_mode != LUPIN_ACCUM_F32;
     if (!ctx->pending.empty())
     {
         // a call joins the batch if it differs from the batch's first call only in camera and accum_counter, and blends with
@@ -1703,7 +1716,7 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
             q->num_frames = 1;
         }
         const bool joins = batchable && ctx->pending_scene == scene && ctx->pending_type == pathtrace_type && memcmp(&a, &b, sizeof(a)) == 0 &&
-                           (fp.pc.accum_counter == 0 || prev == ctx->pending.back().target) && ctx->pending.size() < ctx->batch_frames;
+                           (fp.pc.accum_counter == 0 || prev == ctx->pending.back().target) && ctx->pending.size() < max_frames;
         if (!joins)
         {
             int rc = flush_pending(ctx);
@@ -1713,7 +1726,7 @@ static int pathtrace_impl(LupinContext *ctx, const LupinPathtraceResources *res,
     ctx->pending.push_back({fp, render_target, prev});
     ctx->pending_scene = scene;
     ctx->pending_type = pathtrace_type;
-    if (!batchable || ctx->pending.size() >= ctx->batch_frames) return flush_pending(ctx);
+    if (!batchable || ctx->pending.size() >= max_frames) return flush_pending(ctx);
     return LUPIN_OK;
 }
 

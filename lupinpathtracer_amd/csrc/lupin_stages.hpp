@@ -116,7 +116,7 @@ struct FrameParams
     uint32_t frame_slots;        // slots (pixels of the dispatch) per frame
     uint32_t num_frames;         // frames in this wavefront (1 = a single call)
 };
-constexpr uint32_t LP_MAX_BATCH = 8;
+constexpr uint32_t LP_MAX_BATCH = 16;
 
 // which frame of the batch a slot belongs to, and its pixel slot inside the frame
 __device__ __forceinline__ uint32_t slot_frame(const FrameParams &fp, uint32_t slot, uint32_t &pixel_slot)

@@ -140,7 +140,8 @@ def test_overlapped_frames_keep_accumulation_order(gpu_ctx):
 def test_frames_per_wavefront_equal_one_call_per_wavefront(gpu_ctx, name, ptype):
     """lupin_hip_set_batch_frames: consecutive chained calls run as ONE wavefront.  With a camera that moves every frame, an
     accumulation that restarts in the middle (accum_counter back to 0), a tile-set call and a broken texture chain thrown in,
-    eight frames per wavefront must store exactly what one call per wavefront stores -- and that is the oracle's image."""
+    eight (three, sixteen, the library's own choice) frames per wavefront must store exactly what one call per wavefront stores --
+    and that is the oracle's image."""
     scene, cams = util.load_scene(name, gpu_ctx)
     cam = cams[1 % len(cams)] if name == "materials4" else cams[0]
     W, H, spp, bounces, frames = 88, 56, 2, 5, 11
@@ -180,10 +181,12 @@ def test_frames_per_wavefront_equal_one_call_per_wavefront(gpu_ctx, name, ptype)
         one = render(1)
         eight = render(8)
         three = render(3)
+        sixteen = render(16)
+        auto = render(0)          # the library's choice by dispatch size (sixteen for a frame this small)
     finally:
-        gpu_ctx.set_batch_frames(4)
-    for a, b, c in zip(one, eight, three):
-        assert util.f16_words_differ(a, b) == 0 and util.f16_words_differ(a, c) == 0
+        gpu_ctx.set_batch_frames(0)
+    for a, b, c, d, e in zip(one, eight, three, sixteen, auto):
+        assert util.f16_words_differ(a, b) == 0 and util.f16_words_differ(a, c) == 0 and util.f16_words_differ(a, d) == 0 and util.f16_words_differ(a, e) == 0
     # and the serial result is the oracle's (frames 6.. restart the accumulation, so the last image depends on frames 6..10 only)
     from oracle import oracle
     prev = np.zeros((H, W, 4), np.float16)
@@ -192,7 +195,7 @@ def test_frames_per_wavefront_equal_one_call_per_wavefront(gpu_ctx, name, ptype)
         prev, _ = oracle.pathtrace(scene, W, H, cp, t, bounces, spp, ptype, accum_counter=counter(k), prev_frame=prev)
     assert util.f16_words_differ(one[-3], prev) == 0
     with pytest.raises(api.LupinError):
-        gpu_ctx.set_batch_frames(9)
+        gpu_ctx.set_batch_frames(17)
 
 
 def test_error_behaviour(gpu_ctx):

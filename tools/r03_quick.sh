@@ -5,7 +5,7 @@ run() { python3 tools/scene_bench.py "$@" 2>/dev/null | python3 -c "import json,
 run bistro_class --width 3840 --height 2160 --bounces 16 --steps 16 --warmup 8
 run materials1 --bounces 12 --steps 32 --warmup 16
 run environments1 --bounces 16 --steps 32 --warmup 16
-run cornellbox_builtin --width 1024 --height 1024 --bounces 8 --steps 64 --warmup 32
+run cornellbox_builtin --width 1024 --height 1024 --bounces 8 --steps 64 --warmup 64
 if [ "$1" = "all" ]; then
 run bistro_class --width 3840 --height 2160 --bounces 16 --steps 8 --warmup 4 --type 1
 run bistro_class --width 3840 --height 2160 --bounces 16 --steps 8 --warmup 4 --type 3
