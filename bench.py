@@ -148,12 +148,15 @@ def measure_single_gpu(api, ctx, scene, cam, width, height, bounces, spp, steps,
     rec = {"value": st["path_bounces"] / dt / 1e6, "unit": "Msamples/s", "Mpaths_per_s": st["paths"] / dt / 1e6,
            "ms_per_step": dt / steps * 1e3, "steps": steps, "path_bounces": st["path_bounces"]}
 
-    ksteps = max(1, int(st["frames_per_wavefront"]))   # one full wavefront as the library just ran them: the timed launches are production launches
+    # one full wavefront as the library forms them by default (lupin_hip_set_batch_frames: sixteen calls up to 4 M pixels, eight
+    # above): the timed launches are production launches
+    ksteps = 16 if width * height <= (4 << 20) else 8
     rec["frames_per_wavefront"] = ksteps
     ctx.stats_reset(1)
     for _ in range(ksteps):
         step()
     kst = ctx.stats()
+    assert int(kst["frames_per_wavefront"]) == ksteps, (kst["frames_per_wavefront"], ksteps)
     ctx.stats_reset(2)
     frame[0] -= ksteps          # the same frames again: the counters belong to the launches that were timed
     for _ in range(ksteps):
