@@ -318,7 +318,7 @@ def accuracy_1024spp(api, oracle, ctx, gpu_scene, host_scene, cam, size, bounces
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=16)   # two wavefronts of eight 4K frames; one of sixteen for the smaller per-rank dispatches of --gpus N
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scene", default="bistro_class", help="bistro_class (default) | cornellbox | a fixture scene name")
     ap.add_argument("--width", type=int, default=3840)
