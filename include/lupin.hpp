@@ -103,6 +103,9 @@ class Device   // the reference's (wgpu::Device, wgpu::Queue) pair
     void set_accumulation_mode(int mode) const { check(lupin_hip_set_accumulation_mode(ctx_, mode)); }
     // path state of every frame in flight allocated now instead of at each lane's first pathtrace call
     void reserve_path_state(uint64_t pixels, uint32_t max_bounces, uint32_t samples_per_pixel) const { check(lupin_hip_reserve_path_state(ctx_, pixels, max_bounces, samples_per_pixel)); }
+    // calls per wavefront (1..16; 0 = by dispatch size, the default) and the hierarchy the tracer walks (LUPIN_TRAVERSAL_BINARY / _WIDE)
+    void set_batch_frames(uint32_t frames) const { check(lupin_hip_set_batch_frames(ctx_, frames)); }
+    void set_traversal(int mode) const { check(lupin_hip_set_traversal(ctx_, mode)); }
   private:
     LupinContext *ctx_ = nullptr;
 };

@@ -107,6 +107,8 @@ extern "C" {
     // accumulation mode (f16 running average = reference, or f32 accumulator) and its readback
     pub fn lupin_hip_set_accumulation_mode(ctx: *mut LupinContext, mode: c_int) -> c_int;
     pub fn lupin_hip_reserve_path_state(ctx: *mut LupinContext, pixels: u64, max_bounces: u32, samples_per_pixel: u32) -> c_int;
+    pub fn lupin_hip_set_batch_frames(ctx: *mut LupinContext, frames: u32) -> c_int;
+    pub fn lupin_hip_set_traversal(ctx: *mut LupinContext, mode: c_int) -> c_int;
     pub fn lupin_hip_texture_download_rgba32f(tex: *const LupinTexture, out_pixels: *mut f32) -> c_int;
     pub fn lupin_hip_tonemap_and_fit_aspect(ctx: *mut LupinContext, src: *const LupinTexture, dst_rgba8: *mut u8, w: u32, h: u32,
                                             desc: *const LupinTonemapDesc) -> c_int;
